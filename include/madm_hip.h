@@ -1,0 +1,185 @@
+/*
+ * madm_hip.h -- C ABI of libmadm_hip.so, the MI355X (gfx950) kernel library under the
+ * SD-v1-4 single-timestep feature extractor of MADM.
+ *
+ * The reference (XiaRho/MADM) has no FFI of its own: its hot path is Python calling
+ * third-party torch modules (diffusers 0.25 / peft 0.10).  Each entry point below names
+ * the reference call site whose arithmetic it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is allocated, freed
+ *     or retained by the library; workspaces are sized by the *_workspace_bytes queries;
+ *   - activations are channels-last: [B, H, W, C] == row-major [B*H*W, C] ("tokens");
+ *   - weights are [N][K] row-major, K = KH*KW*(C1+C2) ordered (kh, kw, c), c running
+ *     over source 1 then source 2 (the skip-concat of the reference's up blocks);
+ *   - `dtype` selects the storage/MFMA type of activations and weights:
+ *       MADM_F32  -> f32 storage, v_mfma_f32_16x16x4_f32   (exact-f32 parity mode)
+ *       MADM_BF16 -> bf16 storage, v_mfma_f32_16x16x32_bf16 (fast mode); f32 accumulate;
+ *     bias / time rows / norm parameters / statistics are always f32 (f64 for GN sums);
+ *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous on it,
+ *     capture-safe (no allocation, no synchronisation), re-entrant across streams;
+ *   - return value: 0 = ok, negative = error (see madm_status); the message of the last
+ *     error on the calling thread is returned by madm_last_error().
+ */
+#ifndef MADM_HIP_H
+#define MADM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MADM_ABI_VERSION 1
+
+typedef enum {
+    MADM_OK = 0,
+    MADM_ERR_INVALID_ARG = -1,
+    MADM_ERR_UNSUPPORTED = -2,
+    MADM_ERR_LAUNCH = -3
+} madm_status;
+
+typedef enum { MADM_F32 = 0, MADM_BF16 = 1 } madm_dtype;
+
+typedef enum {
+    MADM_EPI_NONE = 0,
+    /* weight rows interleaved (value_j, gate_j); out[m][j] = value * gelu_erf(gate); the
+     * output has N/2 columns.  diffusers GEGLU inside BasicTransformerBlock.ff, reached
+     * from ldm_diffusers.py:436-440,528-534,553-559 */
+    MADM_EPI_GEGLU = 1
+} madm_epilogue;
+
+int madm_abi_version(void);
+const char* madm_last_error(void);
+
+/* ---------------------------------------------------------------------------------
+ * madm_conv2d_fwd: implicit-GEMM convolution / linear layer on MFMA.
+ *   out[m][n] = epi( sum_k A(m,k) * w[n][k] + bias[n] + rowvec[b(m)][n] ) * 1 + residual[m][n]
+ * A(m,k) gathers the (optionally nearest-2x upsampled, optionally two-source concatenated)
+ * channels-last input at output pixel m = (b, oy, ox) and tap k = (kh, kw, c); zero outside.
+ * Replaces: every nn.Conv2d / nn.Linear executed by diffusers under
+ *   vae_encoder            modeling/meta_arch/ldm_diffusers.py:283-311
+ *   diffusion_unet         modeling/meta_arch/ldm_diffusers.py:454-616
+ *   diffusion_upblock2d / diffusion_cross_attn_upblock2d  ldm_diffusers.py:363-451
+ *     (torch.cat skip concat :370,:409 -> in2/C2; Upsample2D -> upsample=1)
+ *   vae_decoder            modeling/meta_arch/ldm_diffusers.py:314-346
+ * including ResnetBlock2D's "+ time_emb_proj(silu(temb))[:, :, None, None]" (rowvec) and
+ * its output residual / 1x1 shortcut sum, and peft LoRA (mtmadise.py:115-147) through the
+ * K-concatenation [x | s*(xA^T)] x [W | B]^T (in2/C2 with KH=KW=1).
+ * ------------------------------------------------------------------------------- */
+typedef struct {
+    int dtype;            /* madm_dtype */
+    const void* in1;      /* [B, IH, IW, C1] */
+    const void* in2;      /* [B, IH, IW, C2] or NULL when C2 == 0 */
+    int C1, C2;           /* multiples of the K-tile: 64 (bf16) / 32 (f32) elements */
+    int B, IH, IW;        /* source dims (before the optional 2x upsample) */
+    int OH, OW;
+    int KH, KW;           /* 1x1 or 3x3 (any odd size works) */
+    int stride;
+    int pad_t, pad_l;     /* bottom/right padding is implied by OH/OW (zero fill) */
+    int upsample;         /* 1: nearest 2x upsample of the sources before the conv */
+    const void* w;        /* [N][K] of dtype, K = KH*KW*(C1+C2) */
+    int N;                /* output channels; multiple of 4 */
+    const float* bias;    /* [N] or NULL */
+    const float* rowvec;  /* [B][N] or NULL: per-image row added to every pixel */
+    const void* residual; /* [M][ldr] of dtype or NULL; added after the epilogue */
+    int ldr;
+    void* out;            /* [M][ldo] of dtype, M = B*OH*OW */
+    int ldo;
+    int epilogue;         /* madm_epilogue */
+    int splitk;           /* >=1; >1 needs workspace (f32 [splitk][M][N]) */
+    void* workspace;
+    size_t workspace_bytes;
+} madm_conv2d_args;
+
+size_t madm_conv2d_workspace_bytes(const madm_conv2d_args* a);
+/* heuristic split-K for the MI355X grid (256 CUs); returns 1 when the tile grid already fills it */
+int madm_conv2d_suggest_splitk(const madm_conv2d_args* a);
+int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream);
+/* tuning/debug aid: force the workgroup tile (0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64). */
+void madm_debug_set_conv_tile(int tile);
+
+/* ---------------------------------------------------------------------------------
+ * GroupNorm (32 groups in SD-v1-4; any G dividing C), channels-last.
+ *   stats: accumulates per-(b, group) sum and sum of squares into f64 `sums`[B][G][2]
+ *          (caller zeroes `sums` beforehand, e.g. one hipMemsetAsync per forward).
+ *   apply: y = (x - mean) * rstd * gamma + beta, optionally followed by SiLU.
+ * Replaces diffusers ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm,
+ * AttentionBlock.group_norm, conv_norm_out + conv_act
+ * (ldm_diffusers.py:290,299-300,387,435,553,609-610).
+ * ------------------------------------------------------------------------------- */
+int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int G,
+                         double* sums, void* stream);
+int madm_groupnorm_apply(int dtype, const void* x, void* y, int B, int HW, int C, int G,
+                         const double* sums, const float* gamma, const float* beta,
+                         float eps, int silu, void* stream);
+
+/* LayerNorm over the last dim of [M][C] (BasicTransformerBlock.norm1/2/3, eps 1e-5). */
+int madm_layernorm_fwd(int dtype, const void* x, void* y, int M, int C,
+                       const float* gamma, const float* beta, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * madm_attention_fwd: softmax(Q K^T * scale) V, flash style (no L x L matrix in HBM).
+ *   q: [B, Lq, H, D] addressed as q + (b*Lq + i)*ldq + h*D ; k, v likewise with Lk, ldk, ldv
+ *   o: [B, Lq, H, D] with row stride ldo.
+ * Self-attention (Lk = Lq in {4096,1024,256,64}, D in {40,80,160}), cross-attention over
+ * the 77-token prompt (Lk = 77) and the VAE mid-block attention (H = 1, D = 512).
+ * Replaces diffusers Attention / AttnProcessor2_0 (F.scaled_dot_product_attention)
+ * reached from ldm_diffusers.py:297,436-440,528-534,553-559.
+ * ------------------------------------------------------------------------------- */
+typedef struct {
+    int dtype;
+    const void* q; const void* k; const void* v; void* o;
+    int ldq, ldk, ldv, ldo;   /* row strides in elements */
+    int B, H, Lq, Lk, D;
+    float scale;
+} madm_attention_args;
+int madm_attention_fwd(const madm_attention_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Small glue kernels of LdmDiffusers.forward (ldm_diffusers.py:143-217).
+ * ------------------------------------------------------------------------------- */
+/* images [B,3,H,W] f32 in [0,1] (NCHW, as the backbone hands them over) ->
+ * channels-last [B,H,W,Cpad] of dtype holding (x - mean)/std in channels 0..2, zeros above
+ * (ldm_diffusers.py:145-146).  minmax[2] (f32, caller-initialised to +inf/-inf) receives the
+ * normalised min / max so the host can honour the reference's range assert (:147) without
+ * a mid-forward sync. */
+int madm_image_to_nhwc(int dtype, const float* img, void* out, int B, int C, int H, int W,
+                       int Cpad, float mean, float std, float* minmax, void* stream);
+
+/* moments [B*HW][ldm] (dtype; channels 0..3 = posterior mean) ->
+ *   latents_nchw[B,4,h,w] f32 = mean * scaling_factor                     (ldm_diffusers.py:303-308)
+ *   noisy[B*HW][Cpad] dtype   = sqrt_ac[t_b] * latents + sqrt_1mac[t_b] * noise   (:349-360)
+ * noise is the shared [1,4,h,w] f32 tensor (seed 42, :73-75) broadcast over B; extra input
+ * channels 4..Cpad-1 are zero (the K-tile padding of the UNet conv_in). */
+int madm_latents_add_noise(int dtype, const void* moments, int ldm, float scaling,
+                           const float* noise, const float* sqrt_ac, const float* sqrt_1mac,
+                           const int64_t* timesteps, float* latents_nchw, void* noisy,
+                           int B, int HW, int Cpad, void* stream);
+
+/* diffusers Timesteps(320, flip_sin_to_cos=True, freq_shift=0): out[b] = [cos(t f_i) | sin(t f_i)],
+ * f_i = exp(-ln(10000) i / half), written as dtype [B][dim]  (ldm_diffusers.py:498-503). */
+int madm_timestep_embedding(int dtype, const int64_t* timesteps, void* out, int B, int dim,
+                            void* stream);
+
+/* y = silu(x) elementwise over n elements of dtype (time_embedding.act, ResnetBlock2D
+ * nonlinearity on temb). */
+int madm_silu(int dtype, const void* x, void* y, size_t n, void* stream);
+
+/* y[b][c] (f32) = x[b][c] (dtype) + add[b][c] (f32, may be NULL): "emb += res_time_embedding"
+ * (ldm_diffusers.py:505-509) and the dtype->f32 hand-over of time rows to madm_conv2d_fwd. */
+int madm_rows_to_f32(int dtype, const void* x, const float* add, float* y, size_t n, void* stream);
+
+/* channels-last [B*HW][ld] dtype (first C channels) -> NCHW f32 [B,C,H,W]: the tap / sample
+ * tensors returned to the detectron2-side consumers (ldm_diffusers.py:209-217). */
+int madm_nhwc_to_nchw_f32(int dtype, const void* x, int ld, float* out, int B, int C, int HW,
+                          void* stream);
+/* NCHW f32 [B,C,H,W] -> channels-last dtype [B*HW][Cpad] (zero padded). */
+int madm_nchw_f32_to_nhwc(int dtype, const float* x, void* out, int B, int C, int HW, int Cpad,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MADM_HIP_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of libmadm_hip.so (the C ABI declared in include/madm_hip.h).
+
+The library is built in-tree by ``madm_amd/csrc/Makefile`` (``__graft_entry__.build()``).  There is
+no CPU or PyTorch fallback: if the shared object is missing or does not export a symbol, importing
+this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmadm_hip.so")
+
+MADM_F32 = 0
+MADM_BF16 = 1
+EPI_NONE = 0
+EPI_GEGLU = 1
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+
+
+class Conv2dArgs(ctypes.Structure):
+    _fields_ = [
+        ("dtype", c_int),
+        ("in1", c_void_p), ("in2", c_void_p),
+        ("C1", c_int), ("C2", c_int),
+        ("B", c_int), ("IH", c_int), ("IW", c_int),
+        ("OH", c_int), ("OW", c_int),
+        ("KH", c_int), ("KW", c_int),
+        ("stride", c_int),
+        ("pad_t", c_int), ("pad_l", c_int),
+        ("upsample", c_int),
+        ("w", c_void_p),
+        ("N", c_int),
+        ("bias", c_void_p),
+        ("rowvec", c_void_p),
+        ("residual", c_void_p),
+        ("ldr", c_int),
+        ("out", c_void_p),
+        ("ldo", c_int),
+        ("epilogue", c_int),
+        ("splitk", c_int),
+        ("workspace", c_void_p),
+        ("workspace_bytes", c_size_t),
+    ]
+
+
+class AttentionArgs(ctypes.Structure):
+    _fields_ = [
+        ("dtype", c_int),
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p),
+        ("ldq", c_int), ("ldk", c_int), ("ldv", c_int), ("ldo", c_int),
+        ("B", c_int), ("H", c_int), ("Lq", c_int), ("Lk", c_int), ("D", c_int),
+        ("scale", c_float),
+    ]
+
+
+# every symbol include/madm_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("madm_abi_version", c_int, []),
+    ("madm_last_error", ctypes.c_char_p, []),
+    ("madm_conv2d_workspace_bytes", c_size_t, [ctypes.POINTER(Conv2dArgs)]),
+    ("madm_conv2d_suggest_splitk", c_int, [ctypes.POINTER(Conv2dArgs)]),
+    ("madm_conv2d_fwd", c_int, [ctypes.POINTER(Conv2dArgs), c_void_p]),
+    ("madm_debug_set_conv_tile", None, [c_int]),
+    ("madm_groupnorm_stats", c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    ("madm_groupnorm_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_float, c_int, c_void_p]),
+    ("madm_layernorm_fwd", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
+                                   c_void_p]),
+    ("madm_attention_fwd", c_int, [ctypes.POINTER(AttentionArgs), c_void_p]),
+    ("madm_image_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                   c_float, c_void_p, c_void_p]),
+    ("madm_latents_add_noise", c_int, [c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    ("madm_timestep_embedding", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    ("madm_silu", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("madm_rows_to_f32", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("madm_nhwc_to_nchw_f32", c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    ("madm_nchw_f32_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+]
+
+
+class MadmHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or __graft_entry__.build()); madm_amd has no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib.madm_last_error().decode("utf-8", "replace")
+        raise MadmHipError(f"{what} failed (status {rc}): {msg}")

@@ -1,0 +1,259 @@
+// Flash-style attention forward for gfx950 (madm_attention_fwd).
+//
+// Workgroup = NW waves, wave w owns 16 query rows; KV is walked in tiles of NS*16 keys staged in
+// LDS.  Everything is kept "query on lane & 15":
+//   S^T = K Q^T   (MFMA a = K rows, b = Q rows)  -> lane holds one query, keys 4g..4g+3 per sub-tile
+//   row max / sum = in-lane over registers + two xor-shuffles (16, 32)
+//   O^T += V^T P^T (MFMA a = V^T, b = P^T)       -> lane holds one query, 4 consecutive d
+// P never leaves registers: the accumulator registers of S^T are already the b-operand of the
+// second product once the k order of the a-operand (V^T) is permuted to match -- for bf16 that
+// operand comes from ds_read_b64_tr_b16 (a 4-key x 16-d block transposed by the LDS), for f32
+// from four ds_read_b32.
+#include "common.hpp"
+
+namespace {
+
+struct AttnP {
+    const char* q; const char* k; const char* v; char* o;
+    int ldq, ldk, ldv, ldo;
+    int B, H, Lq, Lk, D;
+    float scale_log2;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int NKB, int ND, int NW, int NS>
+struct AttnCfg {
+    static constexpr int ES = sizeof(T);
+    static constexpr int BQ = NW * 16, BKV = NS * 16;
+    static constexpr int QK_CH = NKB * 4;            // 16-byte chunks per Q/K row (padded)
+    static constexpr int QK_ROWB = NKB * 64 + 16;    // +16 B pad: odd number of 16-B slots
+    static constexpr int V_CH = ND * ES;             // chunks per V row: ND*16 elements
+    static constexpr int V_ROWB = ND * 16 * ES + 16;
+    static constexpr size_t LDS_BYTES = (size_t)(BQ + BKV) * QK_ROWB + (size_t)BKV * V_ROWB;
+};
+
+template <typename T, int NKB, int ND, int NW, int NS>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
+    using C = AttnCfg<T, NKB, ND, NW, NS>;
+    constexpr int ES = C::ES;
+    constexpr int NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Ks = Qs + C::BQ * C::QK_ROWB;
+    char* Vs = Ks + C::BKV * C::QK_ROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int bh = blockIdx.y;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * C::BQ;
+    const int dch = p.D * ES / 16;  // valid 16-byte chunks per head row
+
+    // ---- stage the Q tile (rows beyond Lq and chunks beyond D are zero) ----
+    {
+        const char* gq = p.q + ((size_t)(b * p.Lq + q0) * p.ldq + (size_t)h * p.D) * ES;
+        const int rows_valid = p.Lq - q0;
+        for (int idx = tid; idx < C::BQ * C::QK_CH; idx += NT) {
+            const int r = idx / C::QK_CH, c = idx - r * C::QK_CH;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < rows_valid && c < dch)
+                v = *reinterpret_cast<const uint4*>(gq + (size_t)r * p.ldq * ES + c * 16);
+            *reinterpret_cast<uint4*>(Qs + r * C::QK_ROWB + c * 16) = v;
+        }
+    }
+
+    f32x4 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (p.Lk + C::BKV - 1) / C::BKV;
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * C::BKV;
+        __syncthreads();  // previous tile fully consumed (also orders the Q stores on t == 0)
+        {
+            const int rows_valid = p.Lk - k0;
+            const char* gk = p.k + ((size_t)(b * p.Lk + k0) * p.ldk + (size_t)h * p.D) * ES;
+            for (int idx = tid; idx < C::BKV * C::QK_CH; idx += NT) {
+                const int r = idx / C::QK_CH, c = idx - r * C::QK_CH;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (r < rows_valid && c < dch)
+                    v = *reinterpret_cast<const uint4*>(gk + (size_t)r * p.ldk * ES + c * 16);
+                *reinterpret_cast<uint4*>(Ks + r * C::QK_ROWB + c * 16) = v;
+            }
+            const char* gv = p.v + ((size_t)(b * p.Lk + k0) * p.ldv + (size_t)h * p.D) * ES;
+            for (int idx = tid; idx < C::BKV * C::V_CH; idx += NT) {
+                const int r = idx / C::V_CH, c = idx - r * C::V_CH;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (r < rows_valid && c < dch)
+                    v = *reinterpret_cast<const uint4*>(gv + (size_t)r * p.ldv * ES + c * 16);
+                *reinterpret_cast<uint4*>(Vs + r * C::V_ROWB + c * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T for this wave's 16 queries ----
+        f32x4 s[NS];
+#pragma unroll
+        for (int st = 0; st < NS; ++st) s[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const uint4 qf = *reinterpret_cast<const uint4*>(Qs + (wave * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (st * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
+                mma16<T>(kf, qf, s[st]);
+            }
+        }
+        // ---- online softmax (base-2), one query per lane ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + st * 16 + fg * 4 + r;
+                float v = s[st][r] * p.scale_log2;
+                v = (key < p.Lk) ? v : -INFINITY;
+                s[st][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[st][r] - m_new);
+                s[st][r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;  // per lane-group partial; groups are summed at the end
+#pragma unroll
+        for (int d = 0; d < ND; ++d) o[d] *= alpha;
+
+        // ---- O^T += V^T P^T ----
+        if constexpr (sizeof(T) == 2) {
+            static_assert(sizeof(T) != 2 || NS % 2 == 0, "bf16 path pairs key sub-tiles");
+            const int tq = fi >> 2, tp = fi & 3;
+#pragma unroll
+            for (int u = 0; u < NS / 2; ++u) {
+                bf16x8 pf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = (bf16_t)s[2 * u][r];
+                    pf[4 + r] = (bf16_t)s[2 * u + 1][r];
+                }
+                const uint4 pfu = __builtin_bit_cast(uint4, pf);
+                const char* va = Vs + ((2 * u) * 16 + fg * 4 + tq) * C::V_ROWB + tp * 8;
+                const char* vb = va + 16 * C::V_ROWB;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(va + d * 32));
+                    s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(vb + d * 32));
+                    uint2 a0 = __builtin_bit_cast(uint2, x0), a1 = __builtin_bit_cast(uint2, x1);
+                    const uint4 vf = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                    mma16<T>(vf, pfu, o[d]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const float4 pf4 = make_float4(s[st][0], s[st][1], s[st][2], s[st][3]);
+                const uint4 pfu = __builtin_bit_cast(uint4, pf4);
+                const char* vr = Vs + (st * 16 + fg * 4) * C::V_ROWB + fi * 4;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    float4 vf4;
+                    vf4.x = *reinterpret_cast<const float*>(vr + 0 * C::V_ROWB + d * 64);
+                    vf4.y = *reinterpret_cast<const float*>(vr + 1 * C::V_ROWB + d * 64);
+                    vf4.z = *reinterpret_cast<const float*>(vr + 2 * C::V_ROWB + d * 64);
+                    vf4.w = *reinterpret_cast<const float*>(vr + 3 * C::V_ROWB + d * 64);
+                    mma16<T>(__builtin_bit_cast(uint4, vf4), pfu, o[d]);
+                }
+            }
+        }
+    }
+
+    // ---- finish: total row sum over the 4 lane groups, normalise, store 4 consecutive d ----
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_run;
+    const int qi = q0 + wave * 16 + fi;
+    if (qi < p.Lq) {
+        T* orow = reinterpret_cast<T*>(p.o) + (size_t)(b * p.Lq + qi) * p.ldo + (size_t)h * p.D;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const int dd = d * 16 + fg * 4;
+            if (dd < p.D) store4<T>(orow + dd, o[d] * inv);
+        }
+    }
+}
+
+template <typename T, int NKB, int ND, int NW, int NS>
+int launch_attn(const AttnP& p, hipStream_t s) {
+    using C = AttnCfg<T, NKB, ND, NW, NS>;
+    auto kern = attn_kernel<T, NKB, ND, NW, NS>;
+    static bool attr_set = false;  // benign race: idempotent
+    if (!attr_set) {
+        if (C::LDS_BYTES > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+            if (e != hipSuccess) {
+                madm_set_error("attention: cannot raise dynamic LDS to %zu: %s", (size_t)C::LDS_BYTES,
+                               hipGetErrorString(e));
+                return MADM_ERR_LAUNCH;
+            }
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((p.Lq + C::BQ - 1) / C::BQ), (unsigned)(p.B * p.H));
+    kern<<<grid, NW * 64, C::LDS_BYTES, s>>>(p);
+    return madm_check_launch("attn_kernel");
+}
+
+}  // namespace
+
+extern "C" int madm_attention_fwd(const madm_attention_args* a, void* stream) {
+    MADM_REQUIRE(a && a->q && a->k && a->v && a->o, "attention: null pointer");
+    MADM_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->D > 0, "attention: bad dims");
+    const int es = a->dtype == MADM_BF16 ? 2 : 4;
+    MADM_REQUIRE(a->dtype == MADM_F32 || a->dtype == MADM_BF16, "attention: bad dtype");
+    MADM_REQUIRE((a->D * es) % 16 == 0, "attention: head dim %d not 16-byte granular", a->D);
+    MADM_REQUIRE((a->ldq * es) % 16 == 0 && (a->ldk * es) % 16 == 0 && (a->ldv * es) % 16 == 0 &&
+                     (a->ldo * es) % 8 == 0,
+                 "attention: row strides must keep 16-byte alignment");
+    AttnP p;
+    p.q = (const char*)a->q; p.k = (const char*)a->k; p.v = (const char*)a->v; p.o = (char*)a->o;
+    p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
+    p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.D = a->D;
+    p.scale_log2 = a->scale * 1.44269504088896340736f;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->dtype == MADM_BF16) {
+        switch (a->D) {
+            case 40: return launch_attn<bf16_t, 2, 3, 4, 4>(p, s);
+            case 64: return launch_attn<bf16_t, 2, 4, 4, 4>(p, s);
+            case 80: return launch_attn<bf16_t, 3, 5, 4, 4>(p, s);
+            case 160: return launch_attn<bf16_t, 5, 10, 4, 4>(p, s);
+            case 512: return launch_attn<bf16_t, 16, 32, 2, 2>(p, s);
+            default: break;
+        }
+    } else {
+        switch (a->D) {
+            case 40: return launch_attn<float, 3, 3, 4, 4>(p, s);
+            case 64: return launch_attn<float, 4, 4, 4, 4>(p, s);
+            case 80: return launch_attn<float, 5, 5, 4, 4>(p, s);
+            case 160: return launch_attn<float, 10, 10, 4, 4>(p, s);
+            case 512: return launch_attn<float, 32, 32, 1, 1>(p, s);
+            default: break;
+        }
+    }
+    madm_set_error("attention: head dim %d not instantiated (40, 64, 80, 160, 512)", a->D);
+    return MADM_ERR_UNSUPPORTED;
+}

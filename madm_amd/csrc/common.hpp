@@ -1,0 +1,128 @@
+// Shared device/host helpers of libmadm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "madm_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void madm_set_error(const char* fmt, ...);
+int madm_check_launch(const char* what);
+
+#define MADM_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            madm_set_error(__VA_ARGS__);        \
+            return MADM_ERR_INVALID_ARG;        \
+        }                                       \
+    } while (0)
+
+// ---- per-dtype traits: one 16-byte "chunk" holds EPC elements -------------------------
+template <typename T> struct TT;
+template <> struct TT<float> {
+    static constexpr int EPC = 4;
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct TT<bf16_t> {
+    static constexpr int EPC = 8;
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+// unpack a 16-byte chunk into floats / pack floats into a chunk
+template <typename T> __device__ __forceinline__ void chunk_to_f32(const uint4& c, float* f);
+template <> __device__ __forceinline__ void chunk_to_f32<float>(const uint4& c, float* f) {
+    float4 v = __builtin_bit_cast(float4, c);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <> __device__ __forceinline__ void chunk_to_f32<bf16_t>(const uint4& c, float* f) {
+    bf16x8 v = __builtin_bit_cast(bf16x8, c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ uint4 f32_to_chunk(const float* f);
+template <> __device__ __forceinline__ uint4 f32_to_chunk<float>(const float* f) {
+    float4 v = make_float4(f[0], f[1], f[2], f[3]);
+    return __builtin_bit_cast(uint4, v);
+}
+template <> __device__ __forceinline__ uint4 f32_to_chunk<bf16_t>(const float* f) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
+    return __builtin_bit_cast(uint4, v);
+}
+
+// store 4 consecutive elements converted from f32 (8 B for bf16, 16 B for f32)
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+    bf16x4 o;
+    o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    return f32x4{v.x, v.y, v.z, v.w};
+}
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void store2(T* p, float a, float b);
+template <> __device__ __forceinline__ void store2<float>(float* p, float a, float b) {
+    *reinterpret_cast<float2*>(p) = make_float2(a, b);
+}
+template <> __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 o;
+    o[0] = (bf16_t)a; o[1] = (bf16_t)b;
+    *reinterpret_cast<bf16x2*>(p) = o;
+}
+
+// ---- one 16-byte operand chunk per lane -> MFMA ----------------------------------------
+// Both operands are read as "row (lane & 15), 16-byte chunk (lane >> 4)" of a [rows][K] tile.
+// bf16: one v_mfma_f32_16x16x32_bf16 (lane group g holds k = 8g .. 8g+7).
+// f32 : four v_mfma_f32_16x16x4_f32, element s of every lane's float4 at step s -- a
+//       permutation of k that is the same for both operands, so the sum is unchanged.
+// D[i][j] = sum_k a(row i, k) * b(row j, k); lane holds j = lane & 15, i = 4*(lane>>4) + reg.
+template <typename T>
+__device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& c);
+template <>
+__device__ __forceinline__ void mma16<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<float>(const uint4& a, const uint4& b, f32x4& c) {
+    float4 x = __builtin_bit_cast(float4, a), y = __builtin_bit_cast(float4, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, y.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, y.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, y.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, y.w, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+#define MADM_DISPATCH_DTYPE(dtype, ...)                          \
+    do {                                                         \
+        if ((dtype) == MADM_F32) {                               \
+            typedef float T;                                     \
+            __VA_ARGS__;                                         \
+        } else if ((dtype) == MADM_BF16) {                       \
+            typedef bf16_t T;                                    \
+            __VA_ARGS__;                                         \
+        } else {                                                 \
+            madm_set_error("unknown dtype %d", (int)(dtype));    \
+            return MADM_ERR_INVALID_ARG;                         \
+        }                                                        \
+    } while (0)

@@ -1,0 +1,335 @@
+// Implicit-GEMM convolution / linear layer on gfx950 MFMA (madm_conv2d_fwd).
+//
+// GEMM view:  out[m][n] = sum_k A(m,k) * w[n][k],  m = (b, oy, ox), k = (kh, kw, c).
+// Tile: BM x BN outputs per 256-thread workgroup (4 waves as 2 x 2), K tile = 128 bytes per row
+// (64 bf16 / 32 f32).  Both operand tiles live in LDS as [row][8 x 16-byte chunks], chunk index
+// XOR-swizzled with (row & 7) so the ds_read_b128 of "row = lane & 15, chunk = lane >> 4" is
+// bank-conflict free.  Global -> register -> LDS staging, double buffered: the loads of K-tile
+// t+1 are issued before the MFMAs of tile t and written to the other buffer after them; one
+// barrier per K-tile.  The MFMA is issued as D = W_frag x A_frag so that every lane ends up with
+// 4 CONSECUTIVE output channels of one pixel: 8/16-byte stores, vector bias / residual loads.
+#include "common.hpp"
+
+namespace {
+
+struct IgemmP {
+    const char* in1; const char* in2; const char* w;
+    const float* bias; const float* rowvec; const char* residual; char* out; float* ws;
+    int C1, C2, Ctot, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
+    int N, K, M, ldr, ldo, epilogue, splitk, tilesN, nk;
+};
+
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const IgemmP& p, int m, int n, f32x4 v) {
+    if (p.bias) {
+        float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.rowvec) {
+        const int bi = m / (p.OH * p.OW);
+        float4 r = *reinterpret_cast<const float4*>(p.rowvec + (size_t)bi * p.N + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    if (p.epilogue == MADM_EPI_GEGLU) {
+        float o0 = v[0] * gelu_erf_f(v[1]);
+        float o1 = v[2] * gelu_erf_f(v[3]);
+        const int col = n >> 1;
+        if (p.residual) {
+            const T* r = reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + col;
+            o0 += TT<T>::ld(r); o1 += TT<T>::ld(r + 1);
+        }
+        store2<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + col, o0, o1);
+    } else {
+        if (p.residual) {
+            f32x4 r = load4<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
+            v += r;
+        }
+        store4<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+    }
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int BKE = 8 * EPC;            // elements per K tile (128 B per row)
+    constexpr int RA = BM / 32, RB = BN / 32;  // rows staged per thread
+    constexpr int MI = BM / 32, NI = BN / 32;  // 16x16 sub-tiles per wave (wave tile BM/2 x BN/2)
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * (BM + BN) * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const int chunk = tid & 7, lrow = tid >> 3;
+
+    // ---- per-thread gather state: RA pixels of the A tile, RB rows of the weight tile ----
+    int a_b[RA], a_iy[RA], a_ix[RA];
+    const int OHW = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        if (m < p.M) {
+            const int b = m / OHW;
+            const int r = m - b * OHW;
+            const int oy = r / p.OW;
+            const int ox = r - oy * p.OW;
+            a_b[i] = b; a_iy[i] = oy * p.stride - p.pad_t; a_ix[i] = ox * p.stride - p.pad_l;
+        } else {
+            a_b[i] = -1; a_iy[i] = 0; a_ix[i] = 0;
+        }
+    }
+    const char* wrow[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        wrow[i] = (n < p.N) ? p.w + ((size_t)n * p.K + chunk * EPC) * sizeof(T) : nullptr;
+    }
+
+    const int kt0 = (int)(((long long)p.nk * z) / p.splitk);
+    const int kt1 = (int)(((long long)p.nk * (z + 1)) / p.splitk);
+    // tap state of the NEXT tile to load
+    int c0, tr, ts;
+    {
+        const int kbase = kt0 * BKE;
+        const int tap = kbase / p.Ctot;
+        c0 = kbase - tap * p.Ctot;
+        tr = tap / p.KW;
+        ts = tap - tr * p.KW;
+    }
+    const int IHe = p.upsample ? 2 * p.IH : p.IH;
+    const int IWe = p.upsample ? 2 * p.IW : p.IW;
+
+    uint4 ra[RA], rb[RB];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+#define IGEMM_LOAD_TILE(kt)                                                                     \
+    {                                                                                           \
+        const char* src; int Cs, cofs;                                                          \
+        if (c0 < p.C1) { src = p.in1; Cs = p.C1; cofs = c0; }                                   \
+        else           { src = p.in2; Cs = p.C2; cofs = c0 - p.C1; }                            \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                        \
+            uint4 v = zero4;                                                                    \
+            if (a_b[i] >= 0) {                                                                  \
+                int iy = a_iy[i] + tr, ix = a_ix[i] + ts;                                       \
+                if ((unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe) {             \
+                    if (p.upsample) { iy >>= 1; ix >>= 1; }                                     \
+                    const size_t off = ((size_t)(a_b[i] * p.IH + iy) * p.IW + ix) * Cs + cofs + \
+                                       chunk * EPC;                                             \
+                    v = *reinterpret_cast<const uint4*>(src + off * sizeof(T));                 \
+                }                                                                               \
+            }                                                                                   \
+            ra[i] = v;                                                                          \
+        }                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                        \
+            rb[i] = wrow[i] ? *reinterpret_cast<const uint4*>(wrow[i] + (size_t)(kt) * BKE * sizeof(T)) \
+                            : zero4;                                                            \
+        }                                                                                       \
+        c0 += BKE;                                                                              \
+        if (c0 >= p.Ctot) { c0 = 0; ++ts; if (ts == p.KW) { ts = 0; ++tr; } }                   \
+    }
+
+#define IGEMM_STORE_TILE(buf)                                                                   \
+    {                                                                                           \
+        uint4* sA = smem + (buf) * (BM + BN) * 8;                                               \
+        uint4* sB = sA + BM * 8;                                                                \
+        const int sw = chunk ^ (lrow & 7);                                                      \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) sA[(lrow + 32 * i) * 8 + sw] = ra[i];    \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) sB[(lrow + 32 * i) * 8 + sw] = rb[i];    \
+    }
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (kt0 < kt1) {
+        IGEMM_LOAD_TILE(kt0);
+        IGEMM_STORE_TILE(0);
+    }
+    __syncthreads();
+
+    const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = (kt + 1 < kt1);
+        if (more) IGEMM_LOAD_TILE(kt + 1);
+        {
+            const uint4* sA = smem + cur * (BM + BN) * 8;
+            const uint4* sB = sA + BM * 8;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = (fg + 4 * kk) ^ fsw;
+                uint4 af[MI], wf[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = sA[(wm * (BM / 2) + i * 16 + frow) * 8 + c];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wf[j] = sB[(wn * (BN / 2) + j * 16 + frow) * 8 + c];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) mma16<T>(wf[j], af[i], acc[i][j]);
+            }
+        }
+        if (more) IGEMM_STORE_TILE(cur ^ 1);
+        __syncthreads();
+    }
+#undef IGEMM_LOAD_TILE
+#undef IGEMM_STORE_TILE
+
+    // ---- epilogue: lane holds pixel m (lane & 15), channels n .. n+3 (4 * (lane >> 4)) ----
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + frow;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + fg * 4;
+            if (m < p.M && n < p.N) {
+                if (p.splitk > 1) {
+                    f32x4 v = acc[i][j];
+                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    epilogue_store<T>(p, m, n, acc[i][j]);
+                }
+            }
+        }
+    }
+}
+
+// sums the split-K slabs and applies the epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
+    const size_t n4 = (size_t)p.N / 4;
+    const size_t total = (size_t)p.M * n4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / n4);
+        const int n = (int)(idx - (size_t)m * n4) * 4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int zz = 0; zz < p.splitk; ++zz) {
+            float4 t = *reinterpret_cast<const float4*>(p.ws + ((size_t)zz * p.M + m) * p.N + n);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        epilogue_store<T>(p, m, n, v);
+    }
+}
+
+int g_tile_override = 0;  // 0 = heuristic; 1 = 128x128, 2 = 128x64, 3 = 64x64
+
+int pick_tile(int M, int N) {
+    if (g_tile_override) return g_tile_override;
+    auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    // prefer the largest tile that still gives the 256 CUs >= ~1.5 waves of work
+    if (M >= 128 && N >= 128 && tiles(128, 128) >= 384) return 1;
+    if (M >= 128 && tiles(128, 64) >= 256) return 2;
+    return 3;
+}
+
+void tile_dims(int t, int& bm, int& bn) {
+    if (t == 1) { bm = 128; bn = 128; }
+    else if (t == 2) { bm = 128; bn = 64; }
+    else { bm = 64; bn = 64; }
+}
+
+int fill_params(const madm_conv2d_args* a, IgemmP& p) {
+    MADM_REQUIRE(a != nullptr, "conv2d: null args");
+    MADM_REQUIRE(a->dtype == MADM_F32 || a->dtype == MADM_BF16, "conv2d: bad dtype %d", a->dtype);
+    const int bke = (a->dtype == MADM_BF16) ? 64 : 32;
+    MADM_REQUIRE(a->in1 && a->w && a->out, "conv2d: null tensor pointer");
+    MADM_REQUIRE(a->C1 > 0 && a->C1 % bke == 0, "conv2d: C1=%d must be a positive multiple of %d", a->C1, bke);
+    MADM_REQUIRE(a->C2 >= 0 && a->C2 % bke == 0, "conv2d: C2=%d must be a multiple of %d", a->C2, bke);
+    MADM_REQUIRE(a->C2 == 0 || a->in2, "conv2d: C2>0 needs in2");
+    MADM_REQUIRE(a->B > 0 && a->IH > 0 && a->IW > 0 && a->OH > 0 && a->OW > 0, "conv2d: bad dims");
+    MADM_REQUIRE(a->KH > 0 && a->KW > 0 && a->stride > 0, "conv2d: bad kernel/stride");
+    MADM_REQUIRE(a->N > 0 && a->N % 4 == 0, "conv2d: N=%d must be a positive multiple of 4", a->N);
+    MADM_REQUIRE(a->epilogue == MADM_EPI_NONE || a->epilogue == MADM_EPI_GEGLU, "conv2d: bad epilogue");
+    MADM_REQUIRE(a->splitk >= 1, "conv2d: splitk must be >= 1");
+    const int ocols = (a->epilogue == MADM_EPI_GEGLU) ? a->N / 2 : a->N;
+    MADM_REQUIRE(a->ldo >= ocols && a->ldo % 2 == 0, "conv2d: ldo=%d too small/odd for %d columns", a->ldo, ocols);
+    MADM_REQUIRE(a->epilogue == MADM_EPI_GEGLU || a->ldo % 4 == 0, "conv2d: ldo must be a multiple of 4");
+    MADM_REQUIRE(!a->residual || (a->ldr >= ocols && a->ldr % 2 == 0), "conv2d: bad ldr");
+    p.in1 = (const char*)a->in1; p.in2 = (const char*)a->in2; p.w = (const char*)a->w;
+    p.bias = a->bias; p.rowvec = a->rowvec; p.residual = (const char*)a->residual;
+    p.out = (char*)a->out; p.ws = (float*)a->workspace;
+    p.C1 = a->C1; p.C2 = a->C2; p.Ctot = a->C1 + a->C2;
+    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW;
+    p.KH = a->KH; p.KW = a->KW; p.stride = a->stride; p.pad_t = a->pad_t; p.pad_l = a->pad_l;
+    p.upsample = a->upsample ? 1 : 0;
+    p.N = a->N; p.K = a->KH * a->KW * p.Ctot; p.M = a->B * a->OH * a->OW;
+    p.ldr = a->ldr; p.ldo = a->ldo; p.epilogue = a->epilogue;
+    p.nk = p.K / bke;
+    p.splitk = a->splitk > p.nk ? p.nk : a->splitk;
+    if (p.splitk < 1) p.splitk = 1;
+    return MADM_OK;
+}
+
+template <typename T>
+int launch(const IgemmP& p0, hipStream_t s) {
+    IgemmP p = p0;
+    const int t = pick_tile(p.M, p.N);
+    int bm, bn;
+    tile_dims(t, bm, bn);
+    p.tilesN = (p.N + bn - 1) / bn;
+    const int tilesM = (p.M + bm - 1) / bm;
+    dim3 grid((unsigned)(tilesM * p.tilesN), 1, (unsigned)p.splitk);
+    if (t == 1) igemm_kernel<T, 128, 128><<<grid, 256, 0, s>>>(p);
+    else if (t == 2) igemm_kernel<T, 128, 64><<<grid, 256, 0, s>>>(p);
+    else igemm_kernel<T, 64, 64><<<grid, 256, 0, s>>>(p);
+    int rc = madm_check_launch("igemm_kernel");
+    if (rc) return rc;
+    if (p.splitk > 1) {
+        const size_t total = (size_t)p.M * (p.N / 4);
+        unsigned blocks = (unsigned)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        splitk_reduce_kernel<T><<<blocks, 256, 0, s>>>(p);
+        rc = madm_check_launch("splitk_reduce_kernel");
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+void madm_debug_set_conv_tile(int t) { g_tile_override = t; }
+
+size_t madm_conv2d_workspace_bytes(const madm_conv2d_args* a) {
+    if (!a || a->splitk <= 1) return 0;
+    const size_t M = (size_t)a->B * a->OH * a->OW;
+    return (size_t)a->splitk * M * (size_t)a->N * sizeof(float);
+}
+
+int madm_conv2d_suggest_splitk(const madm_conv2d_args* a) {
+    if (!a) return 1;
+    const int bke = (a->dtype == MADM_BF16) ? 64 : 32;
+    const int M = a->B * a->OH * a->OW;
+    const int nk = a->KH * a->KW * (a->C1 + a->C2) / bke;
+    int bm, bn;
+    tile_dims(pick_tile(M, a->N), bm, bn);
+    const long long tiles = (long long)((M + bm - 1) / bm) * ((a->N + bn - 1) / bn);
+    if (tiles >= 192 || nk < 8) return 1;
+    long long s = (512 + tiles - 1) / tiles;
+    if (s > nk / 4) s = nk / 4;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream) {
+    IgemmP p;
+    int rc = fill_params(a, p);
+    if (rc) return rc;
+    if (p.splitk > 1) {
+        const size_t need = (size_t)p.splitk * p.M * (size_t)p.N * sizeof(float);
+        MADM_REQUIRE(a->workspace && a->workspace_bytes >= need,
+                     "conv2d: split-K %d needs %zu workspace bytes, got %zu", p.splitk, need,
+                     a->workspace_bytes);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (a->dtype == MADM_F32) return launch<float>(p, s);
+    return launch<bf16_t>(p, s);
+}
+
+}  // extern "C"

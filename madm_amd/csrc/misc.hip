@@ -1,0 +1,205 @@
+// Glue kernels of LdmDiffusers.forward: layout changes, image normalisation, latent scaling +
+// noise mixing, sinusoidal timestep embedding, SiLU on time rows.  All HBM/launch-bound.
+#include "common.hpp"
+
+namespace {
+
+// NCHW f32 image -> channels-last dtype, (x - mean) / std in the first C channels, zeros above.
+template <typename T>
+__global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restrict__ img, T* __restrict__ out,
+                                                            int B, int C, int HW, int Cpad, float mean,
+                                                            float inv_std, float* minmax) {
+    constexpr int EPC = TT<T>::EPC;
+    const size_t total = (size_t)B * HW;
+    float lo = INFINITY, hi = -INFINITY;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / HW);
+        const int px = (int)(idx - (size_t)b * HW);
+        T* o = out + idx * Cpad;
+        for (int q = 0; q < Cpad / EPC; ++q) {
+            float f[EPC];
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                const int c = q * EPC + j;
+                float v = 0.f;
+                if (c < C) {
+                    v = (img[((size_t)b * C + c) * HW + px] - mean) * inv_std;
+                    lo = fminf(lo, v);
+                    hi = fmaxf(hi, v);
+                }
+                f[j] = v;
+            }
+            *reinterpret_cast<uint4*>(o + q * EPC) = f32_to_chunk<T>(f);
+        }
+    }
+    if (minmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&minmax[0], lo);
+            atomicMax(&minmax[1], hi);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void latents_add_noise_kernel(const T* __restrict__ moments, int ldm,
+                                                                float scaling, const float* __restrict__ noise,
+                                                                const float* __restrict__ sqrt_ac,
+                                                                const float* __restrict__ sqrt_1mac,
+                                                                const int64_t* __restrict__ timesteps,
+                                                                float* __restrict__ latents_nchw,
+                                                                T* __restrict__ noisy, int B, int HW, int Cpad) {
+    constexpr int EPC = TT<T>::EPC;
+    const size_t total = (size_t)B * HW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / HW);
+        const int px = (int)(idx - (size_t)b * HW);
+        const int t = (int)timesteps[b];
+        const float sa = sqrt_ac[t], sn = sqrt_1mac[t];
+        float lat[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            lat[c] = TT<T>::ld(moments + idx * ldm + c) * scaling;
+            if (latents_nchw) latents_nchw[((size_t)b * 4 + c) * HW + px] = lat[c];
+        }
+        T* o = noisy + idx * Cpad;
+        for (int q = 0; q < Cpad / EPC; ++q) {
+            float f[EPC];
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                const int c = q * EPC + j;
+                f[j] = (c < 4) ? sa * lat[c] + sn * noise[(size_t)c * HW + px] : 0.f;
+            }
+            *reinterpret_cast<uint4*>(o + q * EPC) = f32_to_chunk<T>(f);
+        }
+    }
+}
+
+template <typename T>
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ timesteps, T* __restrict__ out, int B,
+                                          int dim) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * half) return;
+    const int b = idx / half, i = idx - b * half;
+    const float freq = expf(-9.210340371976184f * (float)i / (float)half);  // ln(10000)
+    const float arg = (float)timesteps[b] * freq;
+    TT<T>::st(out + (size_t)b * dim + i, cosf(arg));
+    TT<T>::st(out + (size_t)b * dim + half + i, sinf(arg));
+}
+
+template <typename T>
+__global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        TT<T>::st(y + i, silu_f(TT<T>::ld(x + i)));
+}
+
+template <typename T>
+__global__ void rows_to_f32_kernel(const T* __restrict__ x, const float* __restrict__ add, float* __restrict__ y,
+                                   size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = TT<T>::ld(x + i) + (add ? add[i] : 0.f);
+}
+
+// [B*HW][ld] (first C channels) -> [B][C][HW] f32, 32x32 LDS tile transpose
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, int ld, float* __restrict__ out,
+                                                           int C, int HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int hw = hw0 + ty + 8 * k, c = c0 + tx;
+        float v = 0.f;
+        if (hw < HW && c < C) v = TT<T>::ld(x + ((size_t)b * HW + hw) * ld + c);
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, hw = hw0 + tx;
+        if (c < C && hw < HW) out[((size_t)b * C + c) * HW + hw] = tile[tx][ty + 8 * k];
+    }
+}
+
+unsigned grid_for(size_t n, unsigned cap = 2048) {
+    size_t g = (n + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int madm_image_to_nhwc(int dtype, const float* img, void* out, int B, int C, int H, int W, int Cpad, float mean,
+                       float std, float* minmax, void* stream) {
+    MADM_REQUIRE(img && out, "image_to_nhwc: null pointer");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % epc == 0,
+                 "image_to_nhwc: bad dims (C=%d Cpad=%d)", C, Cpad);
+    MADM_REQUIRE(std != 0.f, "image_to_nhwc: std == 0");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)B * H * W;
+    MADM_DISPATCH_DTYPE(dtype, (image_to_nhwc_kernel<T><<<grid_for(total), 256, 0, s>>>(
+                                   img, (T*)out, B, C, H * W, Cpad, mean, 1.0f / std, minmax)));
+    return madm_check_launch("image_to_nhwc_kernel");
+}
+
+int madm_nchw_f32_to_nhwc(int dtype, const float* x, void* out, int B, int C, int HW, int Cpad, void* stream) {
+    return madm_image_to_nhwc(dtype, x, out, B, C, HW, 1, Cpad, 0.f, 1.f, nullptr, stream);
+}
+
+int madm_latents_add_noise(int dtype, const void* moments, int ldm, float scaling, const float* noise,
+                           const float* sqrt_ac, const float* sqrt_1mac, const int64_t* timesteps,
+                           float* latents_nchw, void* noisy, int B, int HW, int Cpad, void* stream) {
+    MADM_REQUIRE(moments && noise && sqrt_ac && sqrt_1mac && timesteps && noisy, "latents_add_noise: null pointer");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(B > 0 && HW > 0 && ldm >= 4 && Cpad >= 4 && Cpad % epc == 0, "latents_add_noise: bad dims");
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (latents_add_noise_kernel<T><<<grid_for((size_t)B * HW), 256, 0, s>>>(
+                                   (const T*)moments, ldm, scaling, noise, sqrt_ac, sqrt_1mac, timesteps,
+                                   latents_nchw, (T*)noisy, B, HW, Cpad)));
+    return madm_check_launch("latents_add_noise_kernel");
+}
+
+int madm_timestep_embedding(int dtype, const int64_t* timesteps, void* out, int B, int dim, void* stream) {
+    MADM_REQUIRE(timesteps && out && B > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const int n = B * dim / 2;
+    MADM_DISPATCH_DTYPE(dtype, (timestep_embedding_kernel<T><<<(n + 255) / 256, 256, 0, s>>>(timesteps, (T*)out, B, dim)));
+    return madm_check_launch("timestep_embedding_kernel");
+}
+
+int madm_silu(int dtype, const void* x, void* y, size_t n, void* stream) {
+    MADM_REQUIRE(x && y && n > 0, "silu: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (silu_kernel<T><<<grid_for(n), 256, 0, s>>>((const T*)x, (T*)y, n)));
+    return madm_check_launch("silu_kernel");
+}
+
+int madm_rows_to_f32(int dtype, const void* x, const float* add, float* y, size_t n, void* stream) {
+    MADM_REQUIRE(x && y && n > 0, "rows_to_f32: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (rows_to_f32_kernel<T><<<grid_for(n), 256, 0, s>>>((const T*)x, add, y, n)));
+    return madm_check_launch("rows_to_f32_kernel");
+}
+
+int madm_nhwc_to_nchw_f32(int dtype, const void* x, int ld, float* out, int B, int C, int HW, void* stream) {
+    MADM_REQUIRE(x && out && B > 0 && C > 0 && HW > 0 && ld >= C, "nhwc_to_nchw: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+    MADM_DISPATCH_DTYPE(dtype, (nhwc_to_nchw_kernel<T><<<grid, 256, 0, s>>>((const T*)x, ld, out, C, HW)));
+    return madm_check_launch("nhwc_to_nchw_kernel");
+}
+
+}  // extern "C"

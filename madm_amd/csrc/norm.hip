@@ -1,0 +1,217 @@
+// GroupNorm (stats + apply[+SiLU]) and LayerNorm on channels-last tensors.  HBM-bound
+// streaming kernels: 16-byte loads/stores per lane, f32 math, f64 cross-block sums.
+#include "common.hpp"
+
+namespace {
+
+// ---- GroupNorm statistics -------------------------------------------------------------
+// grid (splits, B).  A block owns rows [r0, r1) of image b.  Threads are laid out as
+// (column chunk, row lane); every thread keeps per-channel partial sums of its fixed 16-byte
+// column over its rows, adds them into per-channel LDS sums, and the block then folds channels
+// into groups and adds the result to the f64 global sums[b][g][2] (sum, sum of squares).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int G,
+                                                       int rows_per_block, double* sums) {
+    constexpr int EPC = TT<T>::EPC;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][C]
+    float* csum = lds;
+    float* csq = lds + C;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > HW) r1 = HW;
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) lds[c] = 0.f;
+    __syncthreads();
+
+    const int CPR = C / EPC;
+    const int cols = CPR < 256 ? CPR : 256;
+    const int rowlanes = 256 / cols;
+    const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+    if (ty < rowlanes) {
+        const T* xb = x + (size_t)b * HW * C;
+        for (int q = tx; q < CPR; q += cols) {
+            float s[EPC], ss[EPC];
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) { s[j] = 0.f; ss[j] = 0.f; }
+            for (int r = r0 + ty; r < r1; r += rowlanes) {
+                uint4 v = *reinterpret_cast<const uint4*>(xb + (size_t)r * C + q * EPC);
+                float f[EPC];
+                chunk_to_f32<T>(v, f);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                atomicAdd(&csum[q * EPC + j], s[j]);
+                atomicAdd(&csq[q * EPC + j], ss[j]);
+            }
+        }
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double a = 0.0, q = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += (double)csum[c]; q += (double)csq[c]; }
+        atomicAdd(&sums[((size_t)b * G + g) * 2 + 0], a);
+        atomicAdd(&sums[((size_t)b * G + g) * 2 + 1], q);
+    }
+}
+
+// ---- GroupNorm apply (+ optional SiLU) ---------------------------------------------------
+// grid (strips, B).  Per-channel scale/shift of image b are built once per block in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int HW,
+                                                       int C, int G, const double* __restrict__ sums,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int silu) {
+    constexpr int EPC = TT<T>::EPC;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // scale[C], shift[C]
+    float* scale = lds;
+    float* shift = lds + C;
+    const int b = blockIdx.y;
+    const int cpg = C / G;
+    const double cnt = (double)HW * (double)cpg;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const double s = sums[((size_t)b * G + g) * 2 + 0];
+        const double q = sums[((size_t)b * G + g) * 2 + 1];
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = rstd * gamma[c];
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+    }
+    __syncthreads();
+    const int CPR = C / EPC;
+    const size_t total = (size_t)HW * CPR;
+    const T* xb = x + (size_t)b * HW * C;
+    T* yb = y + (size_t)b * HW * C;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % CPR);
+        uint4 v = *reinterpret_cast<const uint4*>(xb + idx * EPC);
+        float f[EPC];
+        chunk_to_f32<T>(v, f);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            float t = f[j] * scale[q * EPC + j] + shift[q * EPC + j];
+            f[j] = silu ? silu_f(t) : t;
+        }
+        *reinterpret_cast<uint4*>(yb + idx * EPC) = f32_to_chunk<T>(f);
+    }
+}
+
+// ---- LayerNorm: one wave per row, row held in registers (C <= 64 * MAXCH * EPC) ---------
+template <typename T, int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, int M,
+                                                        int C, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps) {
+    constexpr int EPC = TT<T>::EPC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int CPR = C / EPC;
+    const T* xr = x + (size_t)row * C;
+    float f[MAXCH][EPC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int q = lane + 64 * i;
+        if (q < CPR) {
+            uint4 v = *reinterpret_cast<const uint4*>(xr + q * EPC);
+            chunk_to_f32<T>(v, f[i]);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) s += f[i][j];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float v2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int q = lane + 64 * i;
+        if (q < CPR) {
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) { const float d = f[i][j] - mean; v2 += d * d; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v2 += __shfl_xor(v2, o);
+    const float rstd = 1.0f / sqrtf(v2 / (float)C + eps);
+    T* yr = y + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int q = lane + 64 * i;
+        if (q < CPR) {
+            float o[EPC];
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                const int c = q * EPC + j;
+                o[j] = (f[i][j] - mean) * rstd * gamma[c] + beta[c];
+            }
+            *reinterpret_cast<uint4*>(yr + q * EPC) = f32_to_chunk<T>(o);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int G, double* sums, void* stream) {
+    MADM_REQUIRE(x && sums, "groupnorm_stats: null pointer");
+    MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_stats: bad dims B=%d HW=%d C=%d G=%d", B, HW, C, G);
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(C % epc == 0, "groupnorm_stats: C=%d must be a multiple of %d", C, epc);
+    MADM_REQUIRE((size_t)2 * C * sizeof(float) <= 64 * 1024, "groupnorm_stats: C=%d too large", C);
+    // enough blocks to fill the chip, at least 32 rows each
+    int splits = (HW + 31) / 32;
+    const int maxsplits = (2048 + B - 1) / B;
+    if (splits > maxsplits) splits = maxsplits;
+    if (splits < 1) splits = 1;
+    const int rows_per_block = (HW + splits - 1) / splits;
+    splits = (HW + rows_per_block - 1) / rows_per_block;
+    dim3 grid((unsigned)splits, (unsigned)B);
+    const size_t shm = (size_t)2 * C * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (gn_stats_kernel<T><<<grid, 256, shm, s>>>((const T*)x, HW, C, G, rows_per_block, sums)));
+    return madm_check_launch("gn_stats_kernel");
+}
+
+int madm_groupnorm_apply(int dtype, const void* x, void* y, int B, int HW, int C, int G, const double* sums,
+                         const float* gamma, const float* beta, float eps, int silu, void* stream) {
+    MADM_REQUIRE(x && y && sums && gamma && beta, "groupnorm_apply: null pointer");
+    MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_apply: bad dims");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(C % epc == 0, "groupnorm_apply: C=%d must be a multiple of %d", C, epc);
+    MADM_REQUIRE((size_t)2 * C * sizeof(float) <= 64 * 1024, "groupnorm_apply: C=%d too large", C);
+    const size_t total = (size_t)HW * (C / epc);
+    size_t strips = (total + 256 * 4 - 1) / (256 * 4);
+    const size_t maxstrips = (size_t)(4096 + B - 1) / B;
+    if (strips > maxstrips) strips = maxstrips;
+    if (strips < 1) strips = 1;
+    dim3 grid((unsigned)strips, (unsigned)B);
+    const size_t shm = (size_t)2 * C * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (gn_apply_kernel<T><<<grid, 256, shm, s>>>((const T*)x, (T*)y, HW, C, G, sums, gamma,
+                                                                        beta, eps, silu)));
+    return madm_check_launch("gn_apply_kernel");
+}
+
+int madm_layernorm_fwd(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta,
+                       float eps, void* stream) {
+    MADM_REQUIRE(x && y && gamma && beta, "layernorm: null pointer");
+    MADM_REQUIRE(M > 0 && C > 0, "layernorm: bad dims");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(C % epc == 0, "layernorm: C=%d must be a multiple of %d", C, epc);
+    MADM_REQUIRE(C / epc <= 64 * 5, "layernorm: C=%d too large (max %d)", C, 64 * 5 * epc);
+    dim3 grid((unsigned)((M + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (layernorm_kernel<T, 5><<<grid, 256, 0, s>>>((const T*)x, (T*)y, M, C, gamma, beta, eps)));
+    return madm_check_launch("layernorm_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+"""Tensor-level wrappers over the C ABI (include/madm_hip.h).
+
+PyTorch is used only for device memory, streams and dtype tags: every function hands raw device
+pointers of CUDA(HIP) tensors to libmadm_hip.so on the current stream.  Activations are
+channels-last 2-D tensors ``[B*H*W, C]``.  There is no fallback path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, Conv2dArgs, AttentionArgs, EPI_NONE, EPI_GEGLU, MADM_F32, MADM_BF16
+
+_DT = {torch.float32: MADM_F32, torch.bfloat16: MADM_BF16}
+
+
+def dtype_code(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise TypeError(f"madm_amd supports float32 and bfloat16 tensors, got {t}")
+
+
+def k_tile(dtype):
+    """K-tile of the MFMA kernels in elements: channel counts must be multiples of it."""
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("madm_amd ops need device tensors (the HIP path has no CPU fallback)")
+
+
+_workspaces = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
+           upsample=False, bias=None, rowvec=None, residual=None, epilogue=EPI_NONE, out=None,
+           splitk=None):
+    """Implicit-GEMM conv / linear.  x1: [B*IH*IW, C1] dense; x2 optional second source (concat);
+    w: packed [N, KH*KW*(C1+C2)]; returns out [B*OH*OW, N] (N/2 columns for GEGLU)."""
+    _need_cuda(x1, w, x2, bias, rowvec, residual, out)
+    C1 = x1.shape[1]
+    C2 = 0 if x2 is None else x2.shape[1]
+    assert x1.is_contiguous() and x1.shape[0] == B * IH * IW, (x1.shape, B, IH, IW)
+    assert x2 is None or (x2.is_contiguous() and x2.shape[0] == x1.shape[0] and x2.dtype == x1.dtype)
+    assert w.dtype == x1.dtype and w.is_contiguous() and tuple(w.shape) == (N, KH * KW * (C1 + C2)), \
+        (w.shape, N, KH, KW, C1, C2)
+    if OH is None:
+        OH = IH * (2 if upsample else 1)
+        OW = IW * (2 if upsample else 1)
+    M = B * OH * OW
+    ocols = N // 2 if epilogue == EPI_GEGLU else N
+    if out is None:
+        out = torch.empty((M, ocols), dtype=x1.dtype, device=x1.device)
+    assert out.shape == (M, ocols) and out.stride(1) == 1 and out.dtype == x1.dtype
+    a = Conv2dArgs()
+    a.dtype = dtype_code(x1)
+    a.in1 = x1.data_ptr()
+    a.in2 = x2.data_ptr() if x2 is not None else None
+    a.C1, a.C2 = C1, C2
+    a.B, a.IH, a.IW, a.OH, a.OW = B, IH, IW, OH, OW
+    a.KH, a.KW, a.stride, a.pad_t, a.pad_l = KH, KW, stride, pad_t, pad_l
+    a.upsample = 1 if upsample else 0
+    a.w = w.data_ptr()
+    a.N = N
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+        a.bias = bias.data_ptr()
+    if rowvec is not None:
+        assert rowvec.dtype == torch.float32 and rowvec.is_contiguous() and tuple(rowvec.shape) == (B, N)
+        a.rowvec = rowvec.data_ptr()
+    if residual is not None:
+        assert residual.dtype == x1.dtype and residual.shape == (M, ocols) and residual.stride(1) == 1
+        a.residual = residual.data_ptr()
+        a.ldr = residual.stride(0)
+    a.out = out.data_ptr()
+    a.ldo = out.stride(0)
+    a.epilogue = epilogue
+    a.splitk = 1
+    if splitk is None:
+        splitk = lib.madm_conv2d_suggest_splitk(ctypes.byref(a))
+    a.splitk = max(1, int(splitk))
+    ws = None
+    if a.splitk > 1:
+        nbytes = lib.madm_conv2d_workspace_bytes(ctypes.byref(a))
+        ws = _workspace(nbytes, x1.device)
+        a.workspace = ws.data_ptr()
+        a.workspace_bytes = ws.numel()
+    check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
+    return out
+
+
+def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=None, splitk=None):
+    """out = x @ w.T (+bias) (+residual); x: [M, K] dense, w: [N, K(+K2)]."""
+    return conv2d(x, w, 1, x.shape[0], 1, N=w.shape[0], x2=x2, bias=bias, residual=residual,
+                  epilogue=epilogue, out=out, splitk=splitk)
+
+
+def groupnorm_stats(x, B, HW, G, sums):
+    """Accumulates (sum, sum of squares) per (b, group) into the f64 tensor ``sums`` [B, G, 2],
+    which the caller has zeroed."""
+    _need_cuda(x, sums)
+    assert x.is_contiguous() and x.shape[0] == B * HW
+    assert sums.dtype == torch.float64 and sums.is_contiguous() and sums.numel() == B * G * 2
+    check(lib.madm_groupnorm_stats(dtype_code(x), x.data_ptr(), B, HW, x.shape[1], G, sums.data_ptr(),
+                                   _stream()), "madm_groupnorm_stats")
+
+
+def groupnorm_apply(x, B, HW, G, sums, gamma, beta, eps, silu, out=None):
+    _need_cuda(x, sums, gamma, beta)
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.madm_groupnorm_apply(dtype_code(x), x.data_ptr(), out.data_ptr(), B, HW, x.shape[1], G,
+                                   sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                   1 if silu else 0, _stream()), "madm_groupnorm_apply")
+    return out
+
+
+def groupnorm(x, B, HW, G, gamma, beta, eps, silu=False, sums=None, out=None):
+    if sums is None:
+        sums = torch.zeros((B, G, 2), dtype=torch.float64, device=x.device)
+    groupnorm_stats(x, B, HW, G, sums)
+    return groupnorm_apply(x, B, HW, G, sums, gamma, beta, eps, silu, out=out)
+
+
+def layernorm(x, gamma, beta, eps, out=None):
+    _need_cuda(x, gamma, beta)
+    assert x.is_contiguous() and x.dim() == 2
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.madm_layernorm_fwd(dtype_code(x), x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
+                                 gamma.data_ptr(), beta.data_ptr(), float(eps), _stream()),
+          "madm_layernorm_fwd")
+    return out
+
+
+def attention(q, k, v, B, H, Lq, Lk, D, scale, out=None):
+    """q: [B*Lq, >=H*D] view with unit column stride (row stride = ld), k/v: [B*Lk, ...] views.
+    Returns o [B*Lq, H*D]."""
+    _need_cuda(q, k, v)
+    for t in (q, k, v):
+        assert t.stride(1) == 1 and t.dtype == q.dtype
+    if out is None:
+        out = torch.empty((B * Lq, H * D), dtype=q.dtype, device=q.device)
+    a = AttentionArgs()
+    a.dtype = dtype_code(q)
+    a.q, a.k, a.v, a.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.B, a.H, a.Lq, a.Lk, a.D = B, H, Lq, Lk, D
+    a.scale = float(scale)
+    check(lib.madm_attention_fwd(ctypes.byref(a), _stream()), "madm_attention_fwd")
+    return out
+
+
+def image_to_nhwc(img, dtype, Cpad, mean, std, minmax=None):
+    _need_cuda(img, minmax)
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4
+    B, C, H, W = img.shape
+    out = torch.empty((B * H * W, Cpad), dtype=dtype, device=img.device)
+    check(lib.madm_image_to_nhwc(dtype_code(dtype), img.data_ptr(), out.data_ptr(), B, C, H, W, Cpad,
+                                 float(mean), float(std), _ptr(minmax), _stream()), "madm_image_to_nhwc")
+    return out
+
+
+def nchw_to_nhwc(x, dtype, Cpad):
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, C, H, W = x.shape
+    out = torch.empty((B * H * W, Cpad), dtype=dtype, device=x.device)
+    check(lib.madm_nchw_f32_to_nhwc(dtype_code(dtype), x.data_ptr(), out.data_ptr(), B, C, H * W, Cpad,
+                                    _stream()), "madm_nchw_f32_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, B, C, H, W):
+    """x: [B*H*W, ld] (first C channels) -> f32 [B, C, H, W]."""
+    _need_cuda(x)
+    assert x.stride(1) == 1
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    check(lib.madm_nhwc_to_nchw_f32(dtype_code(x), x.data_ptr(), x.stride(0), out.data_ptr(), B, C, H * W,
+                                    _stream()), "madm_nhwc_to_nchw_f32")
+    return out
+
+
+def latents_add_noise(moments, scaling, noise, sqrt_ac, sqrt_1mac, timesteps, B, HW, Cpad, h, w):
+    _need_cuda(moments, noise, sqrt_ac, sqrt_1mac, timesteps)
+    assert timesteps.dtype == torch.int64 and noise.dtype == torch.float32 and noise.numel() == 4 * HW
+    latents = torch.empty((B, 4, h, w), dtype=torch.float32, device=moments.device)
+    noisy = torch.empty((B * HW, Cpad), dtype=moments.dtype, device=moments.device)
+    check(lib.madm_latents_add_noise(dtype_code(moments), moments.data_ptr(), moments.stride(0), float(scaling),
+                                     noise.data_ptr(), sqrt_ac.data_ptr(), sqrt_1mac.data_ptr(),
+                                     timesteps.data_ptr(), latents.data_ptr(), noisy.data_ptr(), B, HW, Cpad,
+                                     _stream()), "madm_latents_add_noise")
+    return latents, noisy
+
+
+def timestep_embedding(timesteps, dim, dtype):
+    _need_cuda(timesteps)
+    assert timesteps.dtype == torch.int64
+    B = timesteps.numel()
+    out = torch.empty((B, dim), dtype=dtype, device=timesteps.device)
+    check(lib.madm_timestep_embedding(dtype_code(dtype), timesteps.data_ptr(), out.data_ptr(), B, dim,
+                                      _stream()), "madm_timestep_embedding")
+    return out
+
+
+def silu(x, out=None):
+    _need_cuda(x)
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.madm_silu(dtype_code(x), x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "madm_silu")
+    return out
+
+
+def rows_to_f32(x, add=None):
+    _need_cuda(x, add)
+    assert x.is_contiguous() and (add is None or (add.dtype == torch.float32 and add.is_contiguous()
+                                                   and add.numel() == x.numel()))
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib.madm_rows_to_f32(dtype_code(x), x.data_ptr(), _ptr(add), out.data_ptr(), x.numel(), _stream()),
+          "madm_rows_to_f32")
+    return out

@@ -1,0 +1,51 @@
+"""Weight packing: torch/diffusers parameter layouts -> the [N][K] operands of madm_conv2d_fwd.
+
+K is ordered (kh, kw, c) with c running over source 1 then source 2 (channels-last gather order of
+the implicit GEMM); every source's channel count is zero-padded to the K-tile (64 bf16 / 32 f32).
+"""
+import torch
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def pack_conv_weight(w, dtype, ktile, splits=None):
+    """w: [N, Cin, KH, KW] f32 (nn.Conv2d) -> [N, KH*KW*sum(pad(splits))] of ``dtype``.
+
+    ``splits`` = channel counts of the concatenated sources (default: one source)."""
+    N, Cin, KH, KW = w.shape
+    if splits is None:
+        splits = [Cin]
+    assert sum(splits) == Cin
+    parts = []
+    c0 = 0
+    for c in splits:
+        part = w[:, c0:c0 + c]
+        cp = round_up(c, ktile)
+        if cp != c:
+            part = torch.nn.functional.pad(part, (0, 0, 0, 0, 0, cp - c))
+        parts.append(part)
+        c0 += c
+    wp = torch.cat(parts, dim=1)                       # [N, Cpad, KH, KW]
+    wp = wp.permute(0, 2, 3, 1).contiguous()           # [N, KH, KW, Cpad]
+    return wp.reshape(N, -1).to(dtype).contiguous()
+
+
+def pack_linear_weight(w, dtype, ktile):
+    """w: [N, K] (nn.Linear) -> [N, pad(K)]."""
+    N, K = w.shape
+    Kp = round_up(K, ktile)
+    if Kp != K:
+        w = torch.nn.functional.pad(w, (0, Kp - K))
+    return w.to(dtype).contiguous()
+
+
+def pack_geglu_weight(w, b, dtype, ktile):
+    """diffusers GEGLU.proj: Linear(C, 8C) whose output is chunked (value | gate).  Rows are
+    interleaved (value_j, gate_j) so one lane's 4 consecutive outputs hold two complete pairs."""
+    N, K = w.shape
+    half = N // 2
+    wi = torch.stack([w[:half], w[half:]], dim=1).reshape(N, K)
+    bi = torch.stack([b[:half], b[half:]], dim=1).reshape(N)
+    return pack_linear_weight(wi, dtype, ktile), bi.float().contiguous()

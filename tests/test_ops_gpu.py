@@ -1,0 +1,240 @@
+"""Per-kernel parity on the GPU: every C-ABI entry point against the matching torch-CPU fp32 op
+(SURVEY.md 8c pin K7).  f32 mode must agree to fp32 rounding; bf16 mode is compared with the same
+op evaluated in fp32 on bf16-rounded operands (only accumulation order and output rounding differ)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import to_tokens, from_tokens, rel_err, bf16_round
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
+
+
+def _q(x, dtype):
+    return bf16_round(x) if dtype == torch.bfloat16 else x
+
+
+def _gen(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g)
+
+
+CONV_CASES = [
+    # name, B, Cin(list), H, W, Cout, KH, stride, pad_mode, upsample, tile, splitk
+    ("3x3_s1", 2, [64], 8, 8, 64, 3, 1, "same", False, 0, 1),
+    ("3x3_s1_bigtile", 2, [128], 16, 16, 256, 3, 1, "same", False, 1, 1),
+    ("3x3_s1_tile2", 1, [64], 12, 20, 320, 3, 1, "same", False, 2, 1),
+    ("3x3_s1_ragged", 2, [64], 5, 7, 320, 3, 1, "same", False, 0, 1),
+    ("3x3_s2_unet", 2, [64], 16, 16, 128, 3, 2, "same", False, 0, 1),
+    ("3x3_s2_vae_asym", 2, [64], 16, 16, 128, 3, 2, "asym", False, 0, 1),
+    ("3x3_upsample", 2, [64], 6, 6, 64, 3, 1, "same", True, 0, 1),
+    ("3x3_concat", 2, [128, 64], 8, 8, 192, 3, 1, "same", False, 0, 1),
+    ("3x3_splitk", 2, [256], 4, 4, 128, 3, 1, "same", False, 3, 4),
+    ("3x3_autosplit", 2, [640], 2, 2, 64, 3, 1, "same", False, 0, None),
+    ("1x1", 2, [128], 8, 8, 64, 1, 1, "none", False, 0, 1),
+    ("3x3_tiny_cin", 1, [3], 16, 16, 128, 3, 1, "same", False, 0, 1),
+    ("3x3_tiny_cout", 2, [64], 8, 8, 4, 3, 1, "same", False, 0, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d(cuda, dtype, case):
+    from madm_amd import ops, packing
+    from madm_amd._lib import lib
+    name, B, cins, H, W, Cout, KH, stride, pad_mode, ups, tile, splitk = case
+    kt = ops.k_tile(dtype)
+    xs = [_q(_gen((B, c, H, W), 10 + i), dtype) for i, c in enumerate(cins)]
+    Cin = sum(cins)
+    w = _q(_gen((Cout, Cin, KH, KH), 3) / math.sqrt(Cin * KH * KH), dtype)
+    bias = _gen((Cout,), 4)
+    rowvec = _gen((B, Cout), 5)
+    x = torch.cat(xs, 1)
+    if ups:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    if pad_mode == "same":
+        ref = F.conv2d(x, w, None, stride=stride, padding=KH // 2)
+        pad_t = pad_l = KH // 2
+    elif pad_mode == "asym":
+        ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, None, stride=stride, padding=0)
+        pad_t = pad_l = 0
+    else:
+        ref = F.conv2d(x, w, None, stride=stride, padding=0)
+        pad_t = pad_l = 0
+    OH, OW = ref.shape[2], ref.shape[3]
+    res = _q(_gen((B, Cout, OH, OW), 6), dtype)
+    ref = ref + bias[None, :, None, None] + rowvec[:, :, None, None] + res
+
+    cpads = [packing.round_up(c, kt) for c in cins]
+    toks = [to_tokens(xi, dtype, cp) for xi, cp in zip(xs, cpads)]
+    wp = packing.pack_conv_weight(w, dtype, kt, splits=cins).cuda()
+    lib.madm_debug_set_conv_tile(tile)
+    try:
+        out = ops.conv2d(toks[0], wp, B, H, W, N=Cout, x2=toks[1] if len(toks) > 1 else None, KH=KH, KW=KH,
+                         stride=stride, pad_t=pad_t, pad_l=pad_l, OH=OH, OW=OW, upsample=ups,
+                         bias=bias.cuda(), rowvec=rowvec.cuda(), residual=to_tokens(res, dtype),
+                         splitk=splitk)
+        torch.cuda.synchronize()
+    finally:
+        lib.madm_debug_set_conv_tile(0)
+    got = from_tokens(out, B, OH, OW)
+    e, l2 = rel_err(got, ref)
+    assert e < TOL[dtype], f"{name}: max rel err {e:.3e} l2 {l2:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_linear_geglu(cuda, dtype):
+    from madm_amd import ops, packing
+    kt = ops.k_tile(dtype)
+    M, C = 70, 64
+    x = _q(_gen((M, C), 1), dtype)
+    w = _q(_gen((8 * C, C), 2) / math.sqrt(C), dtype)
+    b = _gen((8 * C,), 3)
+    h = F.linear(x, w, b)
+    val, gate = h.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    wp, bp = packing.pack_geglu_weight(w, b, dtype, kt)
+    out = ops.linear(x.to(dtype).cuda(), wp.cuda(), bias=bp.cuda(), epilogue=ops.EPI_GEGLU)
+    e, l2 = rel_err(out.float().cpu(), ref)
+    assert e < TOL[dtype], f"geglu: {e:.3e} {l2:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8), (2, 320, 16, 16), (1, 128, 33, 17), (2, 1280, 2, 2)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm(cuda, dtype, shape, silu):
+    from madm_amd import ops
+    B, C, H, W = shape
+    x = _q(_gen(shape, 1) * 2.0 + 0.5, dtype)
+    gamma = _gen((C,), 2)
+    beta = _gen((C,), 3)
+    ref = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+    if silu:
+        ref = F.silu(ref)
+    out = ops.groupnorm(to_tokens(x, dtype), B, H * W, 32, gamma.cuda(), beta.cuda(), 1e-5, silu=silu)
+    e, l2 = rel_err(from_tokens(out, B, H, W), ref)
+    assert e < (1e-5 if dtype == torch.float32 else 1e-2), f"{e:.3e} {l2:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("MC", [(70, 320), (16, 640), (5, 1280)])
+def test_layernorm(cuda, dtype, MC):
+    from madm_amd import ops
+    M, C = MC
+    x = _q(_gen((M, C), 1) * 3.0 - 1.0, dtype)
+    gamma = _gen((C,), 2)
+    beta = _gen((C,), 3)
+    ref = F.layer_norm(x, (C,), gamma, beta, eps=1e-5)
+    out = ops.layernorm(x.to(dtype).cuda(), gamma.cuda(), beta.cuda(), 1e-5)
+    e, l2 = rel_err(out.float().cpu(), ref)
+    assert e < (1e-5 if dtype == torch.float32 else 1e-2), f"{e:.3e} {l2:.3e}"
+
+
+ATTN_CASES = [
+    # B, H, Lq, Lk, D
+    (2, 8, 64, 64, 40),
+    (1, 8, 100, 100, 40),
+    (2, 8, 16, 16, 80),
+    (2, 8, 4, 4, 160),
+    (2, 8, 64, 77, 40),     # cross attention over the 77-token prompt
+    (2, 8, 16, 77, 160),
+    (1, 1, 64, 64, 512),    # VAE mid block
+    (1, 2, 200, 333, 64),
+    (1, 8, 1, 1, 160),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[f"B{c[0]}H{c[1]}q{c[2]}k{c[3]}d{c[4]}" for c in ATTN_CASES])
+def test_attention(cuda, dtype, case):
+    from madm_amd import ops
+    B, H, Lq, Lk, D = case
+    q = _q(_gen((B, Lq, H, D), 1), dtype)
+    k = _q(_gen((B, Lk, H, D), 2), dtype)
+    v = _q(_gen((B, Lk, H, D), 3), dtype)
+    scale = D ** -0.5
+    ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), scale=scale)
+    ref = ref.transpose(1, 2).reshape(B * Lq, H * D)
+    # q,k,v as column views of one fused buffer (the layout the QKV projection produces)
+    if Lq == Lk:
+        fused = torch.cat([q.reshape(B * Lq, H * D), k.reshape(B * Lk, H * D), v.reshape(B * Lk, H * D)], 1)
+        fused = fused.to(dtype).cuda()
+        C = H * D
+        qd, kd, vd = fused[:, :C], fused[:, C:2 * C], fused[:, 2 * C:]
+    else:
+        qd = q.reshape(B * Lq, H * D).to(dtype).cuda()
+        kv = torch.cat([k.reshape(B * Lk, H * D), v.reshape(B * Lk, H * D)], 1).to(dtype).cuda()
+        C = H * D
+        kd, vd = kv[:, :C], kv[:, C:]
+    out = ops.attention(qd, kd, vd, B, H, Lq, Lk, D, scale)
+    e, l2 = rel_err(out.float().cpu(), ref)
+    assert e < (2e-5 if dtype == torch.float32 else 1.5e-2), f"{e:.3e} {l2:.3e}"
+
+
+def test_attention_spike(cuda):
+    """Forces the online-softmax rescale: one key dominates late in the sequence."""
+    from madm_amd import ops
+    B, H, L, D = 1, 8, 192, 40
+    q = _gen((B, L, H, D), 1)
+    k = _gen((B, L, H, D), 2)
+    v = _gen((B, L, H, D), 3)
+    k[:, 150] = q[:, 7] * 4.0
+    ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), scale=D ** -0.5)
+    ref = ref.transpose(1, 2).reshape(B * L, H * D)
+    out = ops.attention(q.reshape(B * L, H * D).cuda(), k.reshape(B * L, H * D).cuda(),
+                        v.reshape(B * L, H * D).cuda(), B, H, L, L, D, D ** -0.5)
+    e, l2 = rel_err(out.cpu(), ref)
+    assert e < 2e-5, f"{e:.3e} {l2:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_glue_kernels(cuda, dtype):
+    from madm_amd import ops
+    kt = ops.k_tile(dtype)
+    # image normalisation + layout + range probe
+    img = torch.rand((2, 3, 16, 24), generator=torch.Generator().manual_seed(1))
+    mm = torch.tensor([float("inf"), float("-inf")], device="cuda")
+    t = ops.image_to_nhwc(img.cuda(), dtype, kt, 0.5, 0.5, mm)
+    ref = (img - 0.5) / 0.5
+    got = from_tokens(t, 2, 16, 24)
+    assert rel_err(got[:, :3], ref)[0] < (1e-6 if dtype == torch.float32 else 5e-3)
+    assert got[:, 3:].abs().max().item() == 0.0
+    mmc = mm.cpu()
+    assert abs(mmc[0].item() - ref.min().item()) < 1e-6 and abs(mmc[1].item() - ref.max().item()) < 1e-6
+    # nhwc -> nchw
+    back = ops.nhwc_to_nchw(t, 2, 3, 16, 24).cpu()
+    assert rel_err(back, got[:, :3])[0] == 0.0
+    # timestep embedding
+    ts = torch.tensor([0, 60, 999], dtype=torch.int64)
+    half = 160
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    arg = ts[:, None].float() * freqs[None]
+    ref = torch.cat([torch.cos(arg), torch.sin(arg)], -1)
+    emb = ops.timestep_embedding(ts.cuda(), 320, dtype).float().cpu()
+    assert (emb - ref).abs().max().item() < (2e-5 if dtype == torch.float32 else 5e-3)
+    # silu / rows_to_f32
+    x = _q(_gen((2, 1280), 1), dtype)
+    s = ops.silu(x.to(dtype).cuda()).float().cpu()
+    assert rel_err(s, F.silu(x))[0] < (1e-6 if dtype == torch.float32 else 5e-3)
+    add = _gen((2, 1280), 2)
+    r = ops.rows_to_f32(x.to(dtype).cuda(), add.cuda()).cpu()
+    assert rel_err(r, x + add)[0] < 1e-6
+    # latent scaling + noise mixing
+    B, h, w = 2, 8, 8
+    mom = _q(_gen((B * h * w, 8), 3), dtype)
+    noise = _gen((1, 4, h, w), 4)
+    ac = torch.linspace(0.999, 0.01, 1000)
+    tsb = torch.tensor([0, 60], dtype=torch.int64)
+    lat, noisy = ops.latents_add_noise(mom.to(dtype).cuda(), 0.18215, noise.cuda(), ac.sqrt().cuda(),
+                                       (1 - ac).sqrt().cuda(), tsb.cuda(), B, h * w, kt, h, w)
+    lat_ref = mom[:, :4].reshape(B, h, w, 4).permute(0, 3, 1, 2) * 0.18215
+    assert rel_err(lat.cpu(), lat_ref)[0] < 1e-6
+    noisy_ref = ac.sqrt()[tsb][:, None, None, None] * lat_ref + (1 - ac).sqrt()[tsb][:, None, None, None] * noise
+    gotn = from_tokens(noisy, B, h, w)
+    assert rel_err(gotn[:, :4], noisy_ref)[0] < (1e-6 if dtype == torch.float32 else 5e-3)
+    assert gotn[:, 4:].abs().max().item() == 0.0
