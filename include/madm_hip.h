@@ -82,7 +82,8 @@ typedef struct {
     const void* w;        /* [N][K] of dtype, K = KH*KW*(C1+C2) */
     int N;                /* output channels; multiple of 4 */
     const float* bias;    /* [N] or NULL */
-    const float* rowvec;  /* [B][N] or NULL: per-image row added to every pixel */
+    const float* rowvec;  /* [B][ldrv] or NULL: per-image row added to every pixel */
+    int ldrv;             /* row stride of rowvec in floats (>= N, multiple of 4) */
     const void* residual; /* [M][ldr] of dtype or NULL; added after the epilogue */
     int ldr;
     void* out;            /* [M][ldo] of dtype, M = B*OH*OW */
@@ -101,19 +102,23 @@ int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream);
 void madm_debug_set_conv_tile(int tile);
 
 /* ---------------------------------------------------------------------------------
- * GroupNorm (32 groups in SD-v1-4; any G dividing C), channels-last.
- *   stats: accumulates per-(b, group) sum and sum of squares into f64 `sums`[B][G][2]
- *          (caller zeroes `sums` beforehand, e.g. one hipMemsetAsync per forward).
- *   apply: y = (x - mean) * rstd * gamma + beta, optionally followed by SiLU.
+ * GroupNorm (32 groups in SD-v1-4; any G dividing Ctot), channels-last.  The normalised tensor
+ * has Ctot channels and may be the channel concatenation of several sources (the skip concat
+ * of the up blocks, ldm_diffusers.py:370,409): each call handles one dense source x
+ * [B*HW][C] that occupies channels [c_off, c_off + C) of the concatenation.
+ *   stats: adds the source's per-(b, group) sum and sum of squares into f64 `sums`[B][G][2]
+ *          (caller zeroes `sums` first; one call per source).
+ *   apply: y[.., c_off + c] = (x - mean) * rstd * gamma[c_off + c] + beta[c_off + c], optionally
+ *          followed by SiLU; y has row stride ldy (>= Ctot for a concatenated output).
  * Replaces diffusers ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm,
- * AttentionBlock.group_norm, conv_norm_out + conv_act
- * (ldm_diffusers.py:290,299-300,387,435,553,609-610).
+ * Attention.group_norm (VAE), conv_norm_out + conv_act
+ * (ldm_diffusers.py:290,297,299-300,387,435,553,609-610).
  * ------------------------------------------------------------------------------- */
-int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int G,
-                         double* sums, void* stream);
-int madm_groupnorm_apply(int dtype, const void* x, void* y, int B, int HW, int C, int G,
-                         const double* sums, const float* gamma, const float* beta,
-                         float eps, int silu, void* stream);
+int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int c_off, int Ctot,
+                         int G, double* sums, void* stream);
+int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int HW, int C,
+                         int c_off, int Ctot, int G, const double* sums, const float* gamma,
+                         const float* beta, float eps, int silu, void* stream);
 
 /* LayerNorm over the last dim of [M][C] (BasicTransformerBlock.norm1/2/3, eps 1e-5). */
 int madm_layernorm_fwd(int dtype, const void* x, void* y, int M, int C,
@@ -159,9 +164,10 @@ int madm_latents_add_noise(int dtype, const void* moments, int ldm, float scalin
                            int B, int HW, int Cpad, void* stream);
 
 /* diffusers Timesteps(320, flip_sin_to_cos=True, freq_shift=0): out[b] = [cos(t f_i) | sin(t f_i)],
- * f_i = exp(-ln(10000) i / half), written as dtype [B][dim]  (ldm_diffusers.py:498-503). */
-int madm_timestep_embedding(int dtype, const int64_t* timesteps, void* out, int B, int dim,
-                            void* stream);
+ * f_i = exp(-ln(10000) i / half) handed over as the constant f32 table freqs[dim/2]; written as
+ * dtype [B][dim]  (ldm_diffusers.py:498-503). */
+int madm_timestep_embedding(int dtype, const int64_t* timesteps, const float* freqs, void* out,
+                            int B, int dim, void* stream);
 
 /* y = silu(x) elementwise over n elements of dtype (time_embedding.act, ResnetBlock2D
  * nonlinearity on temb). */
@@ -171,10 +177,15 @@ int madm_silu(int dtype, const void* x, void* y, size_t n, void* stream);
  * (ldm_diffusers.py:505-509) and the dtype->f32 hand-over of time rows to madm_conv2d_fwd. */
 int madm_rows_to_f32(int dtype, const void* x, const float* add, float* y, size_t n, void* stream);
 
-/* channels-last [B*HW][ld] dtype (first C channels) -> NCHW f32 [B,C,H,W]: the tap / sample
- * tensors returned to the detectron2-side consumers (ldm_diffusers.py:209-217). */
-int madm_nhwc_to_nchw_f32(int dtype, const void* x, int ld, float* out, int B, int C, int HW,
-                          void* stream);
+/* y (dtype) = x (f32), n elements: hand-over of f32 conditioning rows (cond_emb, prompt
+ * embeddings; ldm_base.py:877-887) to the compute dtype. */
+int madm_cast_from_f32(int dtype, const float* x, void* y, size_t n, void* stream);
+
+/* channels-last [B*HW][ld] dtype (first C channels) -> channels [c_off, c_off + C) of the NCHW f32
+ * tensor out[B, Ctot, H, W]: the tap / sample tensors returned to the detectron2-side consumers
+ * (ldm_diffusers.py:209-217); c_off/Ctot let two sources form the concatenated 'in'-type taps. */
+int madm_nhwc_to_nchw_f32(int dtype, const void* x, int ld, float* out, int B, int C, int c_off,
+                          int Ctot, int HW, void* stream);
 /* NCHW f32 [B,C,H,W] -> channels-last dtype [B*HW][Cpad] (zero padded). */
 int madm_nchw_f32_to_nhwc(int dtype, const float* x, void* out, int B, int C, int HW, int Cpad,
                           void* stream);

@@ -36,6 +36,7 @@ class Conv2dArgs(ctypes.Structure):
         ("N", c_int),
         ("bias", c_void_p),
         ("rowvec", c_void_p),
+        ("ldrv", c_int),
         ("residual", c_void_p),
         ("ldr", c_int),
         ("out", c_void_p),
@@ -65,9 +66,10 @@ SYMBOLS = [
     ("madm_conv2d_suggest_splitk", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_fwd", c_int, [ctypes.POINTER(Conv2dArgs), c_void_p]),
     ("madm_debug_set_conv_tile", None, [c_int]),
-    ("madm_groupnorm_stats", c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    ("madm_groupnorm_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
-                                     c_void_p, c_void_p, c_float, c_int, c_void_p]),
+    ("madm_groupnorm_stats", c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p]),
+    ("madm_groupnorm_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     ("madm_layernorm_fwd", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
                                    c_void_p]),
     ("madm_attention_fwd", c_int, [ctypes.POINTER(AttentionArgs), c_void_p]),
@@ -75,10 +77,12 @@ SYMBOLS = [
                                    c_float, c_void_p, c_void_p]),
     ("madm_latents_add_noise", c_int, [c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    ("madm_timestep_embedding", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    ("madm_timestep_embedding", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     ("madm_silu", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("madm_rows_to_f32", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    ("madm_nhwc_to_nchw_f32", c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    ("madm_cast_from_f32", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("madm_nhwc_to_nchw_f32", c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p]),
     ("madm_nchw_f32_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 ]
 

@@ -16,7 +16,7 @@ struct IgemmP {
     const char* in1; const char* in2; const char* w;
     const float* bias; const float* rowvec; const char* residual; char* out; float* ws;
     int C1, C2, Ctot, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
-    int N, K, M, ldr, ldo, epilogue, splitk, tilesN, nk;
+    int N, K, M, ldr, ldo, ldrv, epilogue, splitk, tilesN, nk;
 };
 
 template <typename T>
@@ -27,7 +27,7 @@ __device__ __forceinline__ void epilogue_store(const IgemmP& p, int m, int n, f3
     }
     if (p.rowvec) {
         const int bi = m / (p.OH * p.OW);
-        float4 r = *reinterpret_cast<const float4*>(p.rowvec + (size_t)bi * p.N + n);
+        float4 r = *reinterpret_cast<const float4*>(p.rowvec + (size_t)bi * p.ldrv + n);
         v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
     }
     if (p.epilogue == MADM_EPI_GEGLU) {
@@ -258,7 +258,8 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     p.KH = a->KH; p.KW = a->KW; p.stride = a->stride; p.pad_t = a->pad_t; p.pad_l = a->pad_l;
     p.upsample = a->upsample ? 1 : 0;
     p.N = a->N; p.K = a->KH * a->KW * p.Ctot; p.M = a->B * a->OH * a->OW;
-    p.ldr = a->ldr; p.ldo = a->ldo; p.epilogue = a->epilogue;
+    MADM_REQUIRE(!a->rowvec || (a->ldrv >= a->N && a->ldrv % 4 == 0), "conv2d: bad ldrv=%d", a->ldrv);
+    p.ldr = a->ldr; p.ldo = a->ldo; p.ldrv = a->ldrv; p.epilogue = a->epilogue;
     p.nk = p.K / bke;
     p.splitk = a->splitk > p.nk ? p.nk : a->splitk;
     if (p.splitk < 1) p.splitk = 1;

@@ -82,14 +82,13 @@ __global__ __launch_bounds__(256) void latents_add_noise_kernel(const T* __restr
 }
 
 template <typename T>
-__global__ void timestep_embedding_kernel(const int64_t* __restrict__ timesteps, T* __restrict__ out, int B,
-                                          int dim) {
+__global__ void timestep_embedding_kernel(const int64_t* __restrict__ timesteps, const float* __restrict__ freqs,
+                                          T* __restrict__ out, int B, int dim) {
     const int half = dim / 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * half) return;
     const int b = idx / half, i = idx - b * half;
-    const float freq = expf(-9.210340371976184f * (float)i / (float)half);  // ln(10000)
-    const float arg = (float)timesteps[b] * freq;
+    const float arg = (float)timesteps[b] * freqs[i];
     TT<T>::st(out + (size_t)b * dim + i, cosf(arg));
     TT<T>::st(out + (size_t)b * dim + half + i, sinf(arg));
 }
@@ -107,10 +106,16 @@ __global__ void rows_to_f32_kernel(const T* __restrict__ x, const float* __restr
         y[i] = TT<T>::ld(x + i) + (add ? add[i] : 0.f);
 }
 
-// [B*HW][ld] (first C channels) -> [B][C][HW] f32, 32x32 LDS tile transpose
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ x, T* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        TT<T>::st(y + i, x[i]);
+}
+
+// [B*HW][ld] (first C channels) -> channels [c_off, c_off + C) of [B][Ctot][HW] f32, 32x32 LDS tile transpose
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, int ld, float* __restrict__ out,
-                                                           int C, int HW) {
+                                                           int C, int c_off, int Ctot, int HW) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = c0 + ty + 8 * k, hw = hw0 + tx;
-        if (c < C && hw < HW) out[((size_t)b * C + c) * HW + hw] = tile[tx][ty + 8 * k];
+        if (c < C && hw < HW) out[((size_t)b * Ctot + c_off + c) * HW + hw] = tile[tx][ty + 8 * k];
     }
 }
 
@@ -172,11 +177,12 @@ int madm_latents_add_noise(int dtype, const void* moments, int ldm, float scalin
     return madm_check_launch("latents_add_noise_kernel");
 }
 
-int madm_timestep_embedding(int dtype, const int64_t* timesteps, void* out, int B, int dim, void* stream) {
-    MADM_REQUIRE(timesteps && out && B > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad args");
+int madm_timestep_embedding(int dtype, const int64_t* timesteps, const float* freqs, void* out, int B, int dim,
+                            void* stream) {
+    MADM_REQUIRE(timesteps && freqs && out && B > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad args");
     hipStream_t s = (hipStream_t)stream;
     const int n = B * dim / 2;
-    MADM_DISPATCH_DTYPE(dtype, (timestep_embedding_kernel<T><<<(n + 255) / 256, 256, 0, s>>>(timesteps, (T*)out, B, dim)));
+    MADM_DISPATCH_DTYPE(dtype, (timestep_embedding_kernel<T><<<(n + 255) / 256, 256, 0, s>>>(timesteps, freqs, (T*)out, B, dim)));
     return madm_check_launch("timestep_embedding_kernel");
 }
 
@@ -194,11 +200,20 @@ int madm_rows_to_f32(int dtype, const void* x, const float* add, float* y, size_
     return madm_check_launch("rows_to_f32_kernel");
 }
 
-int madm_nhwc_to_nchw_f32(int dtype, const void* x, int ld, float* out, int B, int C, int HW, void* stream) {
-    MADM_REQUIRE(x && out && B > 0 && C > 0 && HW > 0 && ld >= C, "nhwc_to_nchw: bad args");
+int madm_cast_from_f32(int dtype, const float* x, void* y, size_t n, void* stream) {
+    MADM_REQUIRE(x && y && n > 0, "cast_from_f32: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (cast_from_f32_kernel<T><<<grid_for(n), 256, 0, s>>>(x, (T*)y, n)));
+    return madm_check_launch("cast_from_f32_kernel");
+}
+
+int madm_nhwc_to_nchw_f32(int dtype, const void* x, int ld, float* out, int B, int C, int c_off, int Ctot, int HW,
+                          void* stream) {
+    MADM_REQUIRE(x && out && B > 0 && C > 0 && HW > 0 && ld >= C && c_off >= 0 && c_off + C <= Ctot,
+                 "nhwc_to_nchw: bad args");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
-    MADM_DISPATCH_DTYPE(dtype, (nhwc_to_nchw_kernel<T><<<grid, 256, 0, s>>>((const T*)x, ld, out, C, HW)));
+    MADM_DISPATCH_DTYPE(dtype, (nhwc_to_nchw_kernel<T><<<grid, 256, 0, s>>>((const T*)x, ld, out, C, c_off, Ctot, HW)));
     return madm_check_launch("nhwc_to_nchw_kernel");
 }
 

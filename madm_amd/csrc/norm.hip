@@ -10,8 +10,8 @@ namespace {
 // column over its rows, adds them into per-channel LDS sums, and the block then folds channels
 // into groups and adds the result to the f64 global sums[b][g][2] (sum, sum of squares).
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int G,
-                                                       int rows_per_block, double* sums) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int c_off,
+                                                       int Ctot, int G, int rows_per_block, double* sums) {
     constexpr int EPC = TT<T>::EPC;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][C]
     float* csum = lds;
@@ -48,10 +48,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         }
     }
     __syncthreads();
-    const int cpg = C / G;
+    // fold this source's channels [c_off, c_off + C) of the Ctot-channel tensor into its groups
+    const int cpg = Ctot / G;
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        int lo = g * cpg - c_off, hi = (g + 1) * cpg - c_off;
+        if (lo < 0) lo = 0;
+        if (hi > C) hi = C;
+        if (lo >= hi) continue;
         double a = 0.0, q = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += (double)csum[c]; q += (double)csq[c]; }
+        for (int c = lo; c < hi; ++c) { a += (double)csum[c]; q += (double)csq[c]; }
         atomicAdd(&sums[((size_t)b * G + g) * 2 + 0], a);
         atomicAdd(&sums[((size_t)b * G + g) * 2 + 1], q);
     }
@@ -60,8 +65,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 // ---- GroupNorm apply (+ optional SiLU) ---------------------------------------------------
 // grid (strips, B).  Per-channel scale/shift of image b are built once per block in LDS.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int HW,
-                                                       int C, int G, const double* __restrict__ sums,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int ldy,
+                                                       int HW, int C, int c_off, int Ctot, int G,
+                                                       const double* __restrict__ sums,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu) {
     constexpr int EPC = TT<T>::EPC;
@@ -69,10 +75,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     float* scale = lds;
     float* shift = lds + C;
     const int b = blockIdx.y;
-    const int cpg = C / G;
+    const int cpg = Ctot / G;
     const double cnt = (double)HW * (double)cpg;
+    gamma += c_off;
+    beta += c_off;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cpg;
+        const int g = (c_off + c) / cpg;
         const double s = sums[((size_t)b * G + g) * 2 + 0];
         const double q = sums[((size_t)b * G + g) * 2 + 1];
         const double mean = s / cnt;
@@ -87,10 +95,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int CPR = C / EPC;
     const size_t total = (size_t)HW * CPR;
     const T* xb = x + (size_t)b * HW * C;
-    T* yb = y + (size_t)b * HW * C;
+    T* yb = y + (size_t)b * HW * ldy + c_off;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(idx % CPR);
+        const size_t r = idx / CPR;
         uint4 v = *reinterpret_cast<const uint4*>(xb + idx * EPC);
         float f[EPC];
         chunk_to_f32<T>(v, f);
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             float t = f[j] * scale[q * EPC + j] + shift[q * EPC + j];
             f[j] = silu ? silu_f(t) : t;
         }
-        *reinterpret_cast<uint4*>(yb + idx * EPC) = f32_to_chunk<T>(f);
+        *reinterpret_cast<uint4*>(yb + r * ldy + q * EPC) = f32_to_chunk<T>(f);
     }
 }
 
@@ -161,11 +170,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 
 extern "C" {
 
-int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int G, double* sums, void* stream) {
+int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int c_off, int Ctot, int G, double* sums,
+                         void* stream) {
     MADM_REQUIRE(x && sums, "groupnorm_stats: null pointer");
-    MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_stats: bad dims B=%d HW=%d C=%d G=%d", B, HW, C, G);
+    MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && Ctot % G == 0 && c_off >= 0 && c_off + C <= Ctot,
+                 "groupnorm_stats: bad dims B=%d HW=%d C=%d c_off=%d Ctot=%d G=%d", B, HW, C, c_off, Ctot, G);
     const int epc = dtype == MADM_BF16 ? 8 : 4;
-    MADM_REQUIRE(C % epc == 0, "groupnorm_stats: C=%d must be a multiple of %d", C, epc);
+    MADM_REQUIRE(C % epc == 0 && c_off % epc == 0, "groupnorm_stats: C=%d / c_off=%d must be multiples of %d", C, c_off, epc);
     MADM_REQUIRE((size_t)2 * C * sizeof(float) <= 64 * 1024, "groupnorm_stats: C=%d too large", C);
     // enough blocks to fill the chip, at least 32 rows each
     int splits = (HW + 31) / 32;
@@ -177,16 +188,18 @@ int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int G, 
     dim3 grid((unsigned)splits, (unsigned)B);
     const size_t shm = (size_t)2 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    MADM_DISPATCH_DTYPE(dtype, (gn_stats_kernel<T><<<grid, 256, shm, s>>>((const T*)x, HW, C, G, rows_per_block, sums)));
+    MADM_DISPATCH_DTYPE(dtype, (gn_stats_kernel<T><<<grid, 256, shm, s>>>((const T*)x, HW, C, c_off, Ctot, G, rows_per_block, sums)));
     return madm_check_launch("gn_stats_kernel");
 }
 
-int madm_groupnorm_apply(int dtype, const void* x, void* y, int B, int HW, int C, int G, const double* sums,
-                         const float* gamma, const float* beta, float eps, int silu, void* stream) {
+int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int HW, int C, int c_off, int Ctot,
+                         int G, const double* sums, const float* gamma, const float* beta, float eps, int silu,
+                         void* stream) {
     MADM_REQUIRE(x && y && sums && gamma && beta, "groupnorm_apply: null pointer");
-    MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_apply: bad dims");
+    MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && Ctot % G == 0 && c_off >= 0 && c_off + C <= Ctot && ldy >= c_off + C,
+                 "groupnorm_apply: bad dims");
     const int epc = dtype == MADM_BF16 ? 8 : 4;
-    MADM_REQUIRE(C % epc == 0, "groupnorm_apply: C=%d must be a multiple of %d", C, epc);
+    MADM_REQUIRE(C % epc == 0 && c_off % epc == 0 && ldy % epc == 0, "groupnorm_apply: C/c_off/ldy must be multiples of %d", epc);
     MADM_REQUIRE((size_t)2 * C * sizeof(float) <= 64 * 1024, "groupnorm_apply: C=%d too large", C);
     const size_t total = (size_t)HW * (C / epc);
     size_t strips = (total + 256 * 4 - 1) / (256 * 4);
@@ -196,8 +209,8 @@ int madm_groupnorm_apply(int dtype, const void* x, void* y, int B, int HW, int C
     dim3 grid((unsigned)strips, (unsigned)B);
     const size_t shm = (size_t)2 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    MADM_DISPATCH_DTYPE(dtype, (gn_apply_kernel<T><<<grid, 256, shm, s>>>((const T*)x, (T*)y, HW, C, G, sums, gamma,
-                                                                        beta, eps, silu)));
+    MADM_DISPATCH_DTYPE(dtype, (gn_apply_kernel<T><<<grid, 256, shm, s>>>((const T*)x, (T*)y, ldy, HW, C, c_off, Ctot, G, sums,
+                                                                        gamma, beta, eps, silu)));
     return madm_check_launch("gn_apply_kernel");
 }
 

@@ -1,0 +1,329 @@
+"""``LdmRocm``: the MI355X-native replacement of ``LdmDiffusers``
+(/root/reference/modeling/meta_arch/ldm_diffusers.py:17-243) and of its helper functions
+``vae_encoder`` (:283-311), ``vae_decoder`` (:314-346), ``add_noise`` (:349-360) and ``diffusion_unet``
+(:454-616): same names, arguments, return structure and error behaviour, computed by the HIP
+kernels of libmadm_hip.  Swap ``L(LdmDiffusers)`` for ``L(LdmRocm)`` in
+config_files/common/models/mtmadise_multi_lora.py:26-35.
+"""
+import os
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import ops, weights
+from .nn import Tok
+from .sd_unet import UNet2DConditionModel
+from .sd_vae import AutoencoderKL
+
+
+class DDPMSchedule:
+    """SD-v1-4 scheduler_config.json (scaled_linear, 0.00085 -> 0.012, 1000 steps); only the
+    add_noise coefficients are needed (ldm_diffusers.py:359).  Constants built on the host in f32
+    exactly as diffusers does."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.sqrt_ac = self.alphas_cumprod ** 0.5
+        self.sqrt_1mac = (1 - self.alphas_cumprod) ** 0.5
+        self._dev = {}
+
+    def tables(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (self.sqrt_ac.to(device).contiguous(), self.sqrt_1mac.to(device).contiguous())
+        return self._dev[key]
+
+
+def _compute_dtype(m):
+    return getattr(m, "compute_dtype", torch.bfloat16)
+
+
+def _img_tokens(images, dtype, mean=0.0, std=1.0, minmax=None):
+    return Tok(ops.image_to_nhwc(images.float().contiguous(), dtype, ops.k_tile(dtype), mean, std, minmax),
+               images.shape[0], images.shape[2], images.shape[3])
+
+
+@torch.no_grad()
+def vae_encoder(vae, images, encoder_block_indices):
+    """Reference signature (ldm_diffusers.py:283-311): images [B,3,H,W] in [-1,1] (NCHW) ->
+    (latents [B,4,H/8,W/8] f32 = posterior.mean * scaling_factor, list of tap tensors NCHW)."""
+    dtype = _compute_dtype(vae)
+    x = _img_tokens(images, dtype)
+    moments, taps = vae.encode_moments(x, tuple(encoder_block_indices))
+    B, h, w = moments.B, moments.H, moments.W
+    dev = images.device
+    one, zero = _unit_tables(dev)
+    lat, _ = ops.latents_add_noise(moments.t, vae.config.scaling_factor, _zeros(4 * h * w, dev), one, zero,
+                                   _zeros_i64(B, dev), B, h * w, ops.k_tile(dtype), h, w)
+    assert len(encoder_block_indices) == len(taps)
+    return lat, [t.nchw() for t in taps]
+
+
+_const_cache = {}
+
+
+def _unit_tables(dev):
+    key = ("unit", str(dev))
+    if key not in _const_cache:
+        _const_cache[key] = (torch.ones(1, device=dev), torch.zeros(1, device=dev))
+    return _const_cache[key]
+
+
+def _zeros(n, dev):
+    key = ("z", n, str(dev))
+    if key not in _const_cache:
+        _const_cache[key] = torch.zeros(n, device=dev)
+    return _const_cache[key]
+
+
+def _zeros_i64(n, dev):
+    key = ("zi", n, str(dev))
+    if key not in _const_cache:
+        _const_cache[key] = torch.zeros(n, dtype=torch.int64, device=dev)
+    return _const_cache[key]
+
+
+def add_noise(noise_scheduler, latents, timesteps, shared_noise=None):
+    """Reference signature (ldm_diffusers.py:349-360) on NCHW f32 latents (computed in f32)."""
+    B, C, h, w = latents.shape
+    assert C == 4
+    if shared_noise is None:
+        raise NotImplementedError("add_noise without shared_noise is never used by LdmDiffusers.forward (:162-163)")
+    noise = _sized_noise(shared_noise, (h, w))
+    sa, sn = noise_scheduler.tables(latents.device)
+    tok = ops.nchw_to_nhwc(latents.float().contiguous(), torch.float32, 32)
+    _, noisy = ops.latents_add_noise(tok, 1.0, noise.contiguous(), sa, sn,
+                                     timesteps.to(latents.device).long().contiguous(), B, h * w, 32, h, w)
+    return ops.nhwc_to_nchw(noisy, B, 4, h, w)
+
+
+_noise_cache = {}
+
+
+def _sized_noise(shared_noise, hw):
+    """shared_noise resized (bicubic, align_corners=False) when the latent is not 64x64
+    (ldm_diffusers.py:351-353).  A constant of the model: resized once per size and cached."""
+    hw = tuple(int(v) for v in hw)
+    if tuple(shared_noise.shape[2:]) == hw:
+        return shared_noise
+    key = (shared_noise.data_ptr(), hw)
+    if key not in _noise_cache:
+        _noise_cache[key] = torch.nn.functional.interpolate(shared_noise, size=hw, mode="bicubic",
+                                                            align_corners=False).contiguous()
+    return _noise_cache[key]
+
+
+def diffusion_unet(unet, sample, timestep, encoder_hidden_states, res_time_embedding, unet_block_indices,
+                   unet_block_indices_type):
+    """Reference signature (ldm_diffusers.py:454-616): NCHW ``sample`` [B,4,h,w], ``timestep`` int64 [B],
+    ``encoder_hidden_states`` [B,77,768], ``res_time_embedding`` [B,1,1280]|[B,1280]|None ->
+    (namespace(sample=[B,4,h,w]), list of tap tensors NCHW f32)."""
+    dtype = _compute_dtype(unet)
+    B, C, h, w = sample.shape
+    x = Tok(ops.nchw_to_nhwc(sample.float().contiguous(), dtype, ops.k_tile(dtype)), B, h, w)
+    out, taps = _unet_tokens(unet, x, timestep, encoder_hidden_states, res_time_embedding, unet_block_indices,
+                             unet_block_indices_type)
+    return SimpleNamespace(sample=out.nchw(unet.out_channels)), [_tap_nchw(t) for t in taps]
+
+
+def _tap_nchw(t):
+    if isinstance(t, tuple):  # 'in'-type tap: (hidden, skip) concatenated along channels
+        a, b = t
+        return ops.nhwc_to_nchw([a.t, b.t], a.B, [a.C, b.C], a.H, a.W)
+    return t.nchw()
+
+
+def _unet_tokens(unet, x, timestep, encoder_hidden_states, res_time_embedding, unet_block_indices,
+                 unet_block_indices_type):
+    dtype = x.t.dtype
+    B = x.B
+    if not torch.is_tensor(timestep):
+        timestep = torch.tensor([timestep], dtype=torch.int64, device=x.t.device)
+    timestep = timestep.to(torch.int64).reshape(-1).expand(B).contiguous()
+    ehs = encoder_hidden_states
+    assert ehs.dim() == 3 and ehs.shape[0] == B, ehs.shape
+    Lk = ehs.shape[1]
+    ctx = ops.cast_from_f32(ehs.float().contiguous().view(B * Lk, ehs.shape[2]), dtype)
+    cond = None
+    if res_time_embedding is not None:
+        cond = res_time_embedding
+        if cond.dim() == 3 and cond.shape[1] == 1:
+            cond = cond[:, 0]
+        cond = cond.float().contiguous()
+    return unet(x, timestep, ctx, Lk, cond_emb=cond, unet_block_indices=tuple(unet_block_indices),
+                unet_block_indices_type=unet_block_indices_type)
+
+
+class LdmRocm(nn.Module):
+    """Drop-in for ``LdmDiffusers``: same class attributes (consumed by BasePromptTimeGenerator,
+    ldm_base.py:769-774,940-960), constructor arguments, ``forward`` contract and ``_freeze``.
+
+    Extra keyword-only arguments: ``compute_dtype`` (torch.bfloat16 fast mode / torch.float32 exact
+    parity mode), ``weights`` ('pretrained' reads the diffusers snapshot directory given as
+    ``stable_diffusion_name_or_path``; 'synthetic' draws seeded parameters -- no SD checkpoint exists
+    offline), ``seed``, ``check_input_range``."""
+
+    latent_image_size = (64, 64)
+    text_embed_shape = torch.Size([77, 768])
+    unet_time_embed_out_features = 1280
+    uncond_inputs_size = torch.Size([1, 77, 768])
+    feature_size = (512, 512)
+    feature_dims = [512, 512, 2560, 1920, 960, 640, 512, 512]
+    feature_strides = [4, 8, 64, 32, 16, 8, 8, 4]
+    num_groups = 8
+    grouped_indices = [[0], [1], [2], [3], [4], [5], [6], [7]]
+    timesteps = 0
+    input_mean = 0.5
+    input_std = 0.5
+
+    def __init__(self, stable_diffusion_name_or_path, encoder_block_indices, unet_block_indices,
+                 decoder_block_indices, input_range='01', unet_block_indices_type='in', finetune_unet='no',
+                 concat_pixel_shuffle=False, add_latent_noise=-1, norm_latent_noise=False, vae_decoder_loss=False,
+                 input_channel_plus=0, final_fuse_vae_decoder_feat=False, *, compute_dtype=torch.bfloat16,
+                 weights='pretrained', seed=0, check_input_range=True, device='cuda'):
+        super().__init__()
+        self.stable_diffusion_name_or_path = os.path.expanduser(stable_diffusion_name_or_path or "")
+        self.encoder_block_indices = encoder_block_indices
+        self.unet_block_indices = unet_block_indices
+        self.decoder_block_indices = decoder_block_indices
+        self.input_range = input_range
+        assert self.input_range in {'01', '-1+1'}
+        self.unet_block_indices_type = unet_block_indices_type
+        assert self.unet_block_indices_type in {'in', 'after'}
+        self.finetune_unet = finetune_unet
+        assert self.finetune_unet in {'no', 'all', 'attention', 'without cross-attention'}
+        for flag, name in ((concat_pixel_shuffle, 'concat_pixel_shuffle'), (input_channel_plus != 0, 'input_channel_plus'),
+                           (add_latent_noise != -1, 'add_latent_noise'), (norm_latent_noise, 'norm_latent_noise')):
+            if flag:
+                raise NotImplementedError(f"LdmRocm: option {name} of LdmDiffusers (no shipped config enables it, "
+                                          "SURVEY.md Appendix C.11) is not built yet")
+        self.concat_pixel_shuffle = concat_pixel_shuffle
+        self.add_latent_noise = add_latent_noise
+        self.norm_latent_noise = norm_latent_noise
+        self.input_channel_plus = input_channel_plus
+        self.compute_dtype = compute_dtype
+        self.check_input_range = check_input_range
+
+        self.vae = AutoencoderKL()
+        self.unet = UNet2DConditionModel()
+        if weights == 'pretrained':
+            weights_mod = weights_loader
+            weights_mod.load_diffusers_dir(self.vae, self.stable_diffusion_name_or_path, "vae")
+            weights_mod.load_diffusers_dir(self.unet, self.stable_diffusion_name_or_path, "unet")
+        elif weights == 'synthetic':
+            weights_loader.synth_init_(self.vae, seed, "vae.")
+            weights_loader.synth_init_(self.unet, seed, "unet.")
+        else:
+            raise ValueError(weights)
+        self.vae.compute_dtype = compute_dtype
+        self.unet.compute_dtype = compute_dtype
+        self.noise_scheduler = DDPMSchedule()
+
+        rng = torch.Generator().manual_seed(42)
+        self.register_buffer("shared_noise", torch.randn(1, self.vae.latent_channels, *self.latent_image_size,
+                                                         generator=rng).detach())
+        self.register_buffer("uncond_inputs", self._get_uncond_inputs('').detach())
+        self.vae_decoder_loss = vae_decoder_loss
+        self.final_fuse_vae_decoder_feat = final_fuse_vae_decoder_feat
+        if vae_decoder_loss or len(decoder_block_indices) != 0:
+            raise NotImplementedError("LdmRocm: the VAE-decoder branch (ldm_diffusers.py:192-207) is the next row "
+                                      "of the scope table (SURVEY.md 8f rank 1)")
+        self.to(device)
+        self._freeze()
+
+    # ------------------------------------------------------------------ reference surface
+    def _freeze(self):
+        super().train(mode=False)
+        for p in self.parameters():
+            p.requires_grad = False
+        if self.finetune_unet != 'no':
+            if self.finetune_unet == 'all':
+                for p in self.unet.parameters():
+                    p.requires_grad = True
+            elif self.finetune_unet == 'without cross-attention':
+                for name, p in self.unet.named_parameters():
+                    if 'attentions' in name and 'attn2' in name:
+                        if 'to_v' in name:
+                            assert self.unet.state_dict()[name].shape[1] == 768
+                    else:
+                        p.requires_grad = True
+            else:
+                for name, p in self.unet.named_parameters():
+                    if 'attentions' in name:
+                        p.requires_grad = True
+            self.exclude_unused_params()
+
+    def exclude_unused_params(self):
+        """ldm_diffusers.py:123-141 discovers by a dummy backward which UNet parameters feed the last tap.
+        With taps 'after' the last up-block resnet/attention, those are exactly conv_norm_out / conv_out."""
+        last = max(self.unet_block_indices) if len(self.unet_block_indices) else -1
+        n_res = sum(len(b.resnets) for b in self.unet.up_blocks)
+        if last == n_res - 1 or last == -1:
+            for m in (self.unet.conv_norm_out, self.unet.conv_out):
+                for p in m.parameters():
+                    p.requires_grad = False
+
+    def _get_uncond_inputs(self, text):
+        """ldm_diffusers.py:219-243 runs the CLIP text encoder on '' once at construction.  The text
+        encoder is outside the hot path and its weights are not available offline: a precomputed
+        ``uncond_inputs.pt`` next to the snapshot is used when present, otherwise a seeded stand-in
+        of the prompt-embedding scale (ldm_base.py:653)."""
+        p = os.path.join(self.stable_diffusion_name_or_path, "uncond_inputs.pt")
+        if self.stable_diffusion_name_or_path and os.path.exists(p):
+            t = torch.load(p, map_location="cpu").float()
+            assert tuple(t.shape) == tuple(self.uncond_inputs_size)
+            return t
+        return 0.02 * torch.randn(*self.uncond_inputs_size, generator=torch.Generator().manual_seed(4242))
+
+    @torch.no_grad()
+    def forward(self, batched_inputs, input_modal, **kwargs):
+        images = batched_inputs['img']
+        dtype = self.compute_dtype
+        dev = images.device
+        B, _, H, W = images.shape
+        mean, std = (self.input_mean, self.input_std) if self.input_range == '-1+1' else (0.0, 1.0)
+        minmax = torch.tensor([float("inf"), float("-inf")], device=dev) if self.input_range == '-1+1' else None
+        x = _img_tokens(images, dtype, mean, std, minmax)
+        text_prompt = batched_inputs['cond_inputs']
+        res_time_embedding = batched_inputs['cond_emb']
+
+        # latents (vae_encoder) + timesteps + add_noise, the last two fused into one kernel
+        moments, enc_taps = self.vae.encode_moments(x, tuple(self.encoder_block_indices))
+        assert len(self.encoder_block_indices) == len(enc_taps)
+        if 'timestep' in batched_inputs.keys():
+            low_timestep, high_timestep = batched_inputs['timestep'][0], batched_inputs['timestep'][1]
+        else:
+            low_timestep, high_timestep = 0, 1
+        timesteps = torch.randint(low=low_timestep, high=high_timestep, size=(B,), device=dev).long()
+        h, w = moments.H, moments.W
+        noise = _sized_noise(self.shared_noise, (h, w))
+        sa, sn = self.noise_scheduler.tables(dev)
+        latents, noisy = ops.latents_add_noise(moments.t, self.vae.config.scaling_factor, noise, sa, sn, timesteps,
+                                               B, h * w, ops.k_tile(dtype), h, w)
+        self.last_latents = latents
+
+        if 'ema_forward' in kwargs.keys() and kwargs['ema_forward'] and hasattr(self, 'ema_unet'):
+            forward_unet = self.ema_unet
+        else:
+            forward_unet = self.unet
+        sample, unet_taps = _unet_tokens(forward_unet, Tok(noisy, B, h, w), timesteps, text_prompt,
+                                         res_time_embedding, self.unet_block_indices, self.unet_block_indices_type)
+
+        encoder_features = [t.nchw() for t in enc_taps]
+        unet_features = [_tap_nchw(t) for t in unet_taps]
+        decoder_features = []
+        if minmax is not None and self.check_input_range and not torch.cuda.is_current_stream_capturing():
+            lo, hi = minmax.tolist()  # the reference's range assert (:147); one sync per call, like there
+            assert -1 <= lo and hi <= 1
+        if "return_unet_feats" in batched_inputs.keys() and batched_inputs["return_unet_feats"]:
+            return [*encoder_features, *unet_features, *decoder_features], unet_features
+        elif "return_unet_final_output" in kwargs.keys() and kwargs["return_unet_final_output"]:
+            raise NotImplementedError("return_unet_final_output needs the VAE-decoder branch (SURVEY.md 8f rank 1)")
+        else:
+            self.last_sample = sample
+            return [*encoder_features, *unet_features, *decoder_features]
+
+
+weights_loader = weights

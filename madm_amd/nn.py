@@ -1,0 +1,183 @@
+"""Leaf modules of the HIP path: parameter containers with diffusers-compatible names whose
+``forward`` launches libmadm_hip kernels on channels-last token tensors.
+
+fp32 master parameters live in ordinary ``nn.Parameter``s (so ``state_dict()`` / checkpoints /
+``deepcopy`` for the EMA teacher behave as in the reference); the packed [N][K]
+device operands in the compute dtype are derived lazily and re-derived when a parameter's version
+counter moves (optimizer steps, ``load_state_dict``).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+
+
+class Tok:
+    """Channels-last activation: ``t`` is [B*H*W, C] (contiguous), plus its image geometry."""
+    __slots__ = ("t", "B", "H", "W")
+
+    def __init__(self, t, B, H, W):
+        assert t.dim() == 2 and t.shape[0] == B * H * W, (t.shape, B, H, W)
+        self.t, self.B, self.H, self.W = t, B, H, W
+
+    @property
+    def C(self):
+        return self.t.shape[1]
+
+    @property
+    def HW(self):
+        return self.H * self.W
+
+    def like(self, t, H=None, W=None):
+        return Tok(t, self.B, self.H if H is None else H, self.W if W is None else W)
+
+    def nchw(self, C=None):
+        """f32 NCHW copy of the first C channels (hand-over to torch-side consumers)."""
+        return ops.nhwc_to_nchw(self.t, self.B, self.C if C is None else C, self.H, self.W)
+
+
+class _Packed(nn.Module):
+    """Cache of packed operands keyed by (dtype, variant), invalidated by parameter versions."""
+
+    def _versions(self):
+        return tuple(p._version for p in self.parameters(recurse=False)) + \
+            tuple(p.data_ptr() for p in self.parameters(recurse=False))
+
+    def _cache_get(self, key, build):
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        ver = self._versions()
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            val = build()
+        cache[key] = (ver, val)
+        return val
+
+    def __deepcopy__(self, memo):
+        # packed device operands are derived data: drop them from copies (EMA teacher, cmdise.py:307-335)
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_pack_cache":
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+
+class Conv2d(_Packed):
+    """nn.Conv2d parameters (weight [N, Cin, k, k], bias [N]); forward = madm_conv2d_fwd.
+
+    ``asym_pad``: diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) then stride-2 conv."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, asym_pad=False, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.asym_pad = kernel_size, stride, padding, asym_pad
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+
+    @property
+    def n_pad(self):
+        return packing.round_up(self.out_channels, 4)
+
+    def packed(self, dtype, splits=None):
+        key = (dtype, tuple(splits) if splits else None)
+
+        def build():
+            w = self.weight.detach().float()
+            dev = w.device
+            npad = self.n_pad
+            if npad != self.out_channels:
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, npad - self.out_channels))
+            wp = packing.pack_conv_weight(w, dtype, ops.k_tile(dtype), splits)
+            b = None
+            if self.bias is not None:
+                b = self.bias.detach().float()
+                if npad != self.out_channels:
+                    b = torch.nn.functional.pad(b, (0, npad - self.out_channels))
+                b = b.contiguous()
+            return wp.to(dev), b
+
+        return self._cache_get(key, build)
+
+    def out_hw(self, H, W, upsample=False):
+        if upsample:
+            H, W = 2 * H, 2 * W
+        k, s = self.kernel_size, self.stride
+        if self.asym_pad:
+            return (H + 1 - k) // s + 1, (W + 1 - k) // s + 1
+        p = self.padding
+        return (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+
+    def forward(self, x, x2=None, upsample=False, rowvec=None, residual=None, out=None):
+        """x (and optional x2 = channel-concatenated second source) are Tok; returns Tok."""
+        dtype = x.t.dtype
+        splits = None
+        if x2 is not None:
+            splits = [x.C, x2.C]
+            assert x.C + x2.C == self.in_channels, (x.C, x2.C, self.in_channels)
+        wp, b = self.packed(dtype, splits)
+        OH, OW = self.out_hw(x.H, x.W, upsample)
+        pad = 0 if self.asym_pad else self.padding
+        o = ops.conv2d(x.t, wp, x.B, x.H, x.W, N=self.n_pad, x2=None if x2 is None else x2.t,
+                       KH=self.kernel_size, KW=self.kernel_size, stride=self.stride, pad_t=pad, pad_l=pad,
+                       OH=OH, OW=OW, upsample=upsample, bias=b, rowvec=rowvec,
+                       residual=None if residual is None else residual.t, out=out)
+        return Tok(o, x.B, OH, OW)
+
+
+class Linear(_Packed):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+
+    def packed(self, dtype):
+        def build():
+            w = self.weight.detach().float()
+            b = None if self.bias is None else self.bias.detach().float().contiguous()
+            return packing.pack_linear_weight(w, dtype, ops.k_tile(dtype)).to(w.device), b
+
+        return self._cache_get((dtype, "lin"), build)
+
+    def forward(self, x, residual=None, out=None):
+        """x: [M, K] dense 2-D tensor of the compute dtype."""
+        wp, b = self.packed(x.dtype)
+        return ops.linear(x, wp, bias=b, residual=residual, out=out)
+
+
+class GroupNorm(nn.Module):
+    def __init__(self, num_groups, num_channels, eps=1e-5):
+        super().__init__()
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.empty(num_channels))
+        self.bias = nn.Parameter(torch.empty(num_channels))
+
+    def forward(self, x, silu=False, x2=None):
+        """GroupNorm(+SiLU) of x, or of the channel concatenation [x | x2]; returns one dense Tok."""
+        xs = [x.t] if x2 is None else [x.t, x2.t]
+        t = ops.groupnorm(xs, x.B, x.HW, self.num_groups, self.weight.detach(), self.bias.detach(), self.eps,
+                          silu=silu)
+        return x.like(t)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.empty(dim))
+        self.bias = nn.Parameter(torch.empty(dim))
+
+    def forward(self, x):
+        return ops.layernorm(x, self.weight.detach(), self.bias.detach(), self.eps)
+
+
+class Identity(nn.Module):
+    """Parameter-free placeholder keeping diffusers' module indices (Dropout, SiLU)."""
+
+    def forward(self, x):
+        return x

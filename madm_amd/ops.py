@@ -86,8 +86,9 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         assert bias.dtype == torch.float32 and bias.numel() == N
         a.bias = bias.data_ptr()
     if rowvec is not None:
-        assert rowvec.dtype == torch.float32 and rowvec.is_contiguous() and tuple(rowvec.shape) == (B, N)
+        assert rowvec.dtype == torch.float32 and rowvec.stride(1) == 1 and tuple(rowvec.shape) == (B, N)
         a.rowvec = rowvec.data_ptr()
+        a.ldrv = rowvec.stride(0)
     if residual is not None:
         assert residual.dtype == x1.dtype and residual.shape == (M, ocols) and residual.stride(1) == 1
         a.residual = residual.data_ptr()
@@ -115,32 +116,49 @@ def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=No
                   epilogue=epilogue, out=out, splitk=splitk)
 
 
-def groupnorm_stats(x, B, HW, G, sums):
-    """Accumulates (sum, sum of squares) per (b, group) into the f64 tensor ``sums`` [B, G, 2],
-    which the caller has zeroed."""
+def groupnorm_stats(x, B, HW, G, sums, c_off=0, Ctot=None):
+    """Adds (sum, sum of squares) per (b, group) of source ``x`` -- channels [c_off, c_off+C) of a
+    Ctot-channel tensor -- into the f64 tensor ``sums`` [B, G, 2], which the caller has zeroed."""
     _need_cuda(x, sums)
     assert x.is_contiguous() and x.shape[0] == B * HW
     assert sums.dtype == torch.float64 and sums.is_contiguous() and sums.numel() == B * G * 2
-    check(lib.madm_groupnorm_stats(dtype_code(x), x.data_ptr(), B, HW, x.shape[1], G, sums.data_ptr(),
-                                   _stream()), "madm_groupnorm_stats")
+    C = x.shape[1]
+    check(lib.madm_groupnorm_stats(dtype_code(x), x.data_ptr(), B, HW, C, c_off, C if Ctot is None else Ctot, G,
+                                   sums.data_ptr(), _stream()), "madm_groupnorm_stats")
 
 
-def groupnorm_apply(x, B, HW, G, sums, gamma, beta, eps, silu, out=None):
+def groupnorm_apply(x, B, HW, G, sums, gamma, beta, eps, silu, out=None, c_off=0, Ctot=None):
     _need_cuda(x, sums, gamma, beta)
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    C = x.shape[1]
+    Ctot = C if Ctot is None else Ctot
     if out is None:
-        out = torch.empty_like(x)
-    check(lib.madm_groupnorm_apply(dtype_code(x), x.data_ptr(), out.data_ptr(), B, HW, x.shape[1], G,
-                                   sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
+        out = torch.empty((x.shape[0], Ctot), dtype=x.dtype, device=x.device)
+    assert out.stride(1) == 1 and out.shape[1] >= Ctot and gamma.numel() == Ctot
+    check(lib.madm_groupnorm_apply(dtype_code(x), x.data_ptr(), out.data_ptr(), out.stride(0), B, HW, C, c_off,
+                                   Ctot, G, sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
                                    1 if silu else 0, _stream()), "madm_groupnorm_apply")
     return out
 
 
-def groupnorm(x, B, HW, G, gamma, beta, eps, silu=False, sums=None, out=None):
+def groupnorm(xs, B, HW, G, gamma, beta, eps, silu=False, sums=None):
+    """GroupNorm(+SiLU) of the channel concatenation of the sources ``xs`` (a tensor or a list of
+    [B*HW, C_i] tensors); returns the normalised [B*HW, sum C_i] tensor."""
+    if isinstance(xs, torch.Tensor):
+        xs = [xs]
+    Ctot = sum(x.shape[1] for x in xs)
     if sums is None:
-        sums = torch.zeros((B, G, 2), dtype=torch.float64, device=x.device)
-    groupnorm_stats(x, B, HW, G, sums)
-    return groupnorm_apply(x, B, HW, G, sums, gamma, beta, eps, silu, out=out)
+        sums = torch.zeros((B, G, 2), dtype=torch.float64, device=xs[0].device)
+    off = 0
+    for x in xs:
+        groupnorm_stats(x, B, HW, G, sums, off, Ctot)
+        off += x.shape[1]
+    out = torch.empty((xs[0].shape[0], Ctot), dtype=xs[0].dtype, device=xs[0].device)
+    off = 0
+    for x in xs:
+        groupnorm_apply(x, B, HW, G, sums, gamma, beta, eps, silu, out=out, c_off=off, Ctot=Ctot)
+        off += x.shape[1]
+    return out
 
 
 def layernorm(x, gamma, beta, eps, out=None):
@@ -192,13 +210,29 @@ def nchw_to_nhwc(x, dtype, Cpad):
     return out
 
 
-def nhwc_to_nchw(x, B, C, H, W):
-    """x: [B*H*W, ld] (first C channels) -> f32 [B, C, H, W]."""
+def nhwc_to_nchw(xs, B, C, H, W):
+    """xs: tensor or list of [B*H*W, ld_i] tensors whose leading channels (C, or a list of counts)
+    are concatenated into one f32 [B, sum C_i, H, W] tensor."""
+    if isinstance(xs, torch.Tensor):
+        xs, C = [xs], [C]
+    _need_cuda(*xs)
+    Ctot = sum(C)
+    out = torch.empty((B, Ctot, H, W), dtype=torch.float32, device=xs[0].device)
+    off = 0
+    for x, c in zip(xs, C):
+        assert x.stride(1) == 1 and x.shape[1] >= c
+        check(lib.madm_nhwc_to_nchw_f32(dtype_code(x), x.data_ptr(), x.stride(0), out.data_ptr(), B, c, off, Ctot,
+                                        H * W, _stream()), "madm_nhwc_to_nchw_f32")
+        off += c
+    return out
+
+
+def cast_from_f32(x, dtype):
     _need_cuda(x)
-    assert x.stride(1) == 1
-    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
-    check(lib.madm_nhwc_to_nchw_f32(dtype_code(x), x.data_ptr(), x.stride(0), out.data_ptr(), B, C, H * W,
-                                    _stream()), "madm_nhwc_to_nchw_f32")
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib.madm_cast_from_f32(dtype_code(dtype), x.data_ptr(), out.data_ptr(), x.numel(), _stream()),
+          "madm_cast_from_f32")
     return out
 
 
@@ -214,13 +248,21 @@ def latents_add_noise(moments, scaling, noise, sqrt_ac, sqrt_1mac, timesteps, B,
     return latents, noisy
 
 
-def timestep_embedding(timesteps, dim, dtype):
-    _need_cuda(timesteps)
-    assert timesteps.dtype == torch.int64
+def timestep_freqs(dim, device):
+    """Constant table f_i = exp(-ln(10000) * i / (dim/2)) of diffusers' Timesteps (host-built once)."""
+    import math
+    half = dim // 2
+    return torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half).to(device)
+
+
+def timestep_embedding(timesteps, freqs, dtype):
+    _need_cuda(timesteps, freqs)
+    assert timesteps.dtype == torch.int64 and freqs.dtype == torch.float32
     B = timesteps.numel()
+    dim = 2 * freqs.numel()
     out = torch.empty((B, dim), dtype=dtype, device=timesteps.device)
-    check(lib.madm_timestep_embedding(dtype_code(dtype), timesteps.data_ptr(), out.data_ptr(), B, dim,
-                                      _stream()), "madm_timestep_embedding")
+    check(lib.madm_timestep_embedding(dtype_code(dtype), timesteps.data_ptr(), freqs.data_ptr(), out.data_ptr(),
+                                      B, dim, _stream()), "madm_timestep_embedding")
     return out
 
 

@@ -1,0 +1,494 @@
+"""SD-v1-4 ``UNet2DConditionModel`` on the HIP path (diffusers 0.25 module/parameter names).
+
+Replaces the diffusers modules the reference drives from
+modeling/meta_arch/ldm_diffusers.py:454-616 (``diffusion_unet``), :363-398 (``diffusion_upblock2d``)
+and :401-451 (``diffusion_cross_attn_upblock2d``).  Activations are channels-last ``Tok``s, the
+skip ``torch.cat`` is a second gather source of the conv kernel, ``Upsample2D`` is folded into the
+following conv's gather, Q/K/V projections are one fused GEMM and LoRA (peft, mtmadise.py:115-147)
+is a K-concatenated side GEMM.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+from .nn import Tok, Conv2d, Linear, GroupNorm, LayerNorm, Identity, _Packed
+from ._lib import EPI_GEGLU
+
+LORA_PAD = 64  # K-extension of a LoRA-augmented GEMM (>= sum of the fused ranks), one bf16 K-tile
+
+
+# ----------------------------------------------------------------------------- LoRA
+class LoraLinear(nn.Module):
+    """peft-0.10-shaped wrapper: ``base_layer`` + ``lora_A/lora_B[adapter]``; the reference selects
+    the adapter by writing ``module._active_adapter`` (mtmadise.py:144-147)."""
+
+    def __init__(self, base_layer):
+        super().__init__()
+        self.base_layer = base_layer
+        self.lora_A = nn.ModuleDict()
+        self.lora_B = nn.ModuleDict()
+        self.scaling = {}
+        self._active_adapter = []
+        self._disable_adapters = False
+
+    in_features = property(lambda self: self.base_layer.in_features)
+    out_features = property(lambda self: self.base_layer.out_features)
+
+    def update_layer(self, name, r, lora_alpha, generator=None):
+        a = Linear(self.in_features, r, bias=False)
+        b = Linear(r, self.out_features, bias=False)
+        dev = self.base_layer.weight.device
+        with torch.no_grad():  # init_lora_weights="gaussian": A ~ N(0, 1/r), B = 0
+            a.weight.copy_(torch.empty(r, self.in_features).normal_(mean=0.0, std=1.0 / r, generator=generator))
+            b.weight.zero_()
+        self.lora_A[name] = a.to(dev)
+        self.lora_B[name] = b.to(dev)
+        self.scaling[name] = lora_alpha / r
+
+    def active(self):
+        if self._disable_adapters:
+            return []
+        act = self._active_adapter if isinstance(self._active_adapter, (list, tuple)) else [self._active_adapter]
+        return [n for n in act if n in self.lora_A]
+
+
+def _base(m):
+    return m.base_layer if isinstance(m, LoraLinear) else m
+
+
+class _FusedProj(_Packed):
+    """Several Linear layers sharing one input, run as ONE GEMM: out = x @ [W_0; W_1; ...]^T.
+    With active LoRA adapters the GEMM's K is extended by LORA_PAD columns:
+        t   = x @ [s_0 A_0; s_1 A_1; ...]^T              ([M, LORA_PAD], a skinny GEMM)
+        out = [x | t] @ [[W_0 | B_0 0 ..]; [W_1 | 0 B_1 ..]; ...]^T
+    which equals base(x) + B(A x) * (alpha / r) per layer (peft lora.Linear)."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.__dict__["_layers"] = layers  # not registered: the owners register them
+
+    def _versions(self):
+        v = []
+        for l in self._layers:
+            for p in l.parameters():
+                v.append((p._version, p.data_ptr()))
+            if isinstance(l, LoraLinear):
+                v.append(tuple(l.active()))
+        return tuple(v)
+
+    def _build(self, dtype):
+        kt = ops.k_tile(dtype)
+        bases = [_base(l) for l in self._layers]
+        W = torch.cat([b.weight.detach().float() for b in bases], 0)
+        dev = W.device
+        bias = None
+        if any(b.bias is not None for b in bases):
+            bias = torch.cat([b.bias.detach().float() if b.bias is not None
+                              else torch.zeros(b.out_features, device=dev) for b in bases]).contiguous()
+        lora = [(i, l, n) for i, l in enumerate(self._layers) if isinstance(l, LoraLinear) for n in l.active()]
+        A_packed = None
+        if lora:
+            rows = sum(l.lora_A[n].weight.shape[0] for _, l, n in lora)
+            assert rows <= LORA_PAD, f"fused LoRA rank {rows} exceeds {LORA_PAD}"
+            K = W.shape[1]
+            A = torch.zeros(LORA_PAD, K, device=dev)
+            Bx = torch.zeros(W.shape[0], LORA_PAD, device=dev)
+            n_off = [0]
+            for b in bases:
+                n_off.append(n_off[-1] + b.out_features)
+            r0 = 0
+            for i, l, n in lora:
+                a = l.lora_A[n].weight.detach().float()
+                r = a.shape[0]
+                A[r0:r0 + r] = a * l.scaling[n]
+                Bx[n_off[i]:n_off[i + 1], r0:r0 + r] = l.lora_B[n].weight.detach().float()
+                r0 += r
+            A_packed = packing.pack_linear_weight(A, dtype, kt)
+            Kp = packing.round_up(K, kt)
+            Wp = torch.cat([torch.nn.functional.pad(W, (0, Kp - K)), Bx], 1).to(dtype).contiguous()
+        else:
+            Wp = packing.pack_linear_weight(W, dtype, kt)
+        return Wp, bias, A_packed
+
+    def forward(self, x, residual=None):
+        Wp, bias, A = self._cache_get((x.dtype,), lambda: self._build(x.dtype))
+        if A is None:
+            return ops.linear(x, Wp, bias=bias, residual=residual)
+        t = ops.linear(x, A)
+        return ops.linear(x, Wp, bias=bias, residual=residual, x2=t)
+
+
+# ----------------------------------------------------------------------------- transformer
+class Attention(nn.Module):
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.dim_head = heads, dim_head
+        self.scale = dim_head ** -0.5
+        self.is_cross = cross_attention_dim is not None
+        kv = cross_attention_dim if self.is_cross else query_dim
+        self.to_q = Linear(query_dim, inner, bias=False)
+        self.to_k = Linear(kv, inner, bias=False)
+        self.to_v = Linear(kv, inner, bias=False)
+        self.to_out = nn.ModuleList([Linear(inner, query_dim, bias=True), Identity()])
+
+    def _fused(self, key, names):
+        f = self.__dict__.get(key)
+        layers = [self.to_out[0] if n == "to_out" else getattr(self, n) for n in names]
+        if f is None or any(a is not b for a, b in zip(f._layers, layers)):
+            f = _FusedProj(layers)
+            self.__dict__[key] = f
+        return f
+
+    def forward(self, x, B, L, ctx=None, Lk=None, residual=None):
+        """x: [B*L, C] normalised tokens; ctx: [B*Lk, 768] for cross attention; returns
+        to_out(attn) + residual."""
+        C = self.heads * self.dim_head
+        if not self.is_cross:
+            qkv = self._fused("_f_qkv", ("to_q", "to_k", "to_v"))(x)
+            q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+            Lk = L
+        else:
+            q = self._fused("_f_q", ("to_q",))(x)
+            kv = self._fused("_f_kv", ("to_k", "to_v"))(ctx)
+            k, v = kv[:, :C], kv[:, C:]
+        o = ops.attention(q, k, v, B, self.heads, L, Lk, self.dim_head, self.scale)
+        return self._fused("_f_out", ("to_out",))(o, residual=residual)
+
+
+class GEGLU(_Packed):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+
+    def _versions(self):
+        return tuple((p._version, p.data_ptr()) for p in self.proj.parameters())
+
+    def forward(self, x):
+        def build():
+            w, b = packing.pack_geglu_weight(self.proj.weight.detach().float(), self.proj.bias.detach().float(),
+                                             x.dtype, ops.k_tile(x.dtype))
+            return w, b
+        w, b = self._cache_get((x.dtype,), build)
+        return ops.linear(x, w, bias=b, epilogue=EPI_GEGLU)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), Identity(), Linear(dim * mult, dim)])
+
+    def forward(self, x, residual=None):
+        return self.net[2](self.net[0](x), residual=residual)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, dim_head, cross_attention_dim):
+        super().__init__()
+        self.norm1 = LayerNorm(dim)
+        self.attn1 = Attention(dim, None, heads, dim_head)
+        self.norm2 = LayerNorm(dim)
+        self.attn2 = Attention(dim, cross_attention_dim, heads, dim_head)
+        self.norm3 = LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, h, B, L, ctx, Lk):
+        h = self.attn1(self.norm1(h), B, L, residual=h)
+        h = self.attn2(self.norm2(h), B, L, ctx=ctx, Lk=Lk, residual=h)
+        h = self.ff(self.norm3(h), residual=h)
+        return h
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, heads, dim_head, in_channels, cross_attention_dim=768):
+        super().__init__()
+        inner = heads * dim_head
+        self.norm = GroupNorm(32, in_channels, eps=1e-6)
+        self.proj_in = Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
+        self.proj_out = Conv2d(inner, in_channels, 1)
+
+    def forward(self, x, ctx, Lk):
+        h = self.proj_in(self.norm(x))
+        t = h.t
+        for blk in self.transformer_blocks:
+            t = blk(t, x.B, x.HW, ctx, Lk)
+        return self.proj_out(x.like(t), residual=x)
+
+
+# ----------------------------------------------------------------------------- resnet & samplers
+class ResnetBlock2D(nn.Module):
+    def __init__(self, in_channels, out_channels, temb_channels=1280, eps=1e-5):
+        super().__init__()
+        self.norm1 = GroupNorm(32, in_channels, eps=eps)
+        self.conv1 = Conv2d(in_channels, out_channels, 3, padding=1)
+        self.time_emb_proj = Linear(temb_channels, out_channels) if temb_channels is not None else None
+        self.norm2 = GroupNorm(32, out_channels, eps=eps)
+        self.dropout = Identity()
+        self.conv2 = Conv2d(out_channels, out_channels, 3, padding=1)
+        self.nonlinearity = Identity()
+        self.conv_shortcut = Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+
+    def forward(self, x, temb_row=None, skip=None):
+        """x (+ optional skip = second concat source) -> Tok.  ``temb_row``: f32 [B, Cout] =
+        time_emb_proj(silu(emb)) (computed for all resnets at once by the UNet)."""
+        if skip is None:
+            h = self.norm1(x, silu=True)
+            h = self.conv1(h, rowvec=temb_row)
+            res = x if self.conv_shortcut is None else self.conv_shortcut(x)
+        else:
+            # GroupNorm over the concatenated channels: the concat exists only as the normalised
+            # copy written by the two-source GN; the 1x1 shortcut reads the two sources directly.
+            h = self.norm1(x, silu=True, x2=skip)
+            h = self.conv1(h, rowvec=temb_row)
+            res = self.conv_shortcut(x, x2=skip)
+        h = self.norm2(h, silu=True)
+        return self.conv2(h, residual=res)
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, channels, padding=1):
+        super().__init__()
+        self.conv = Conv2d(channels, channels, 3, stride=2, padding=padding, asym_pad=(padding == 0))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = Conv2d(channels, channels, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(x, upsample=True)
+
+
+# ----------------------------------------------------------------------------- blocks
+class CrossAttnDownBlock2D(nn.Module):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, out_channels, heads, add_downsample=True, num_layers=2):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels) for i in range(num_layers)])
+        self.attentions = nn.ModuleList(
+            [Transformer2DModel(heads, out_channels // heads, out_channels) for _ in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+
+class DownBlock2D(nn.Module):
+    has_cross_attention = False
+
+    def __init__(self, in_channels, out_channels, add_downsample=False, num_layers=2):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels) for i in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+
+class UNetMidBlock2DCrossAttn(nn.Module):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, heads):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(in_channels, in_channels), ResnetBlock2D(in_channels, in_channels)])
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, in_channels // heads, in_channels)])
+
+
+class UpBlock2D(nn.Module):
+    has_cross_attention = False
+
+    def __init__(self, in_channels, prev_output_channel, out_channels, add_upsample=True, num_layers=3):
+        super().__init__()
+        self.resnets = nn.ModuleList()
+        for i in range(num_layers):
+            res_skip = in_channels if i == num_layers - 1 else out_channels
+            res_in = prev_output_channel if i == 0 else out_channels
+            self.resnets.append(ResnetBlock2D(res_in + res_skip, out_channels))
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+
+class CrossAttnUpBlock2D(nn.Module):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, prev_output_channel, out_channels, heads, add_upsample=True, num_layers=3):
+        super().__init__()
+        self.resnets = nn.ModuleList()
+        self.attentions = nn.ModuleList()
+        for i in range(num_layers):
+            res_skip = in_channels if i == num_layers - 1 else out_channels
+            res_in = prev_output_channel if i == 0 else out_channels
+            self.resnets.append(ResnetBlock2D(res_in + res_skip, out_channels))
+            self.attentions.append(Transformer2DModel(heads, out_channels // heads, out_channels))
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim):
+        super().__init__()
+        self.linear_1 = Linear(in_channels, time_embed_dim)
+        self.act = Identity()
+        self.linear_2 = Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, t_emb, residual=None):
+        return self.linear_2(ops.silu(self.linear_1(t_emb)), residual=residual)
+
+
+class UNet2DConditionModel(nn.Module):
+    """Parameter tree == diffusers' SD-v1-4 UNet (859,520,964 parameters at the default widths)."""
+
+    def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), heads=8,
+                 cross_attention_dim=768, layers_per_block=2):
+        super().__init__()
+        boc = tuple(block_out_channels)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.block_out_channels, self.cross_attention_dim = boc, cross_attention_dim
+        time_embed_dim = boc[0] * 4
+        self.time_embed_dim = time_embed_dim
+        self.conv_in = Conv2d(in_channels, boc[0], 3, padding=1)
+        self.time_proj = Identity()
+        self.time_embedding = TimestepEmbedding(boc[0], time_embed_dim)
+        self.down_blocks = nn.ModuleList()
+        out_ch = boc[0]
+        for i, ch in enumerate(boc):
+            in_ch, out_ch = out_ch, ch
+            if i != len(boc) - 1:
+                self.down_blocks.append(CrossAttnDownBlock2D(in_ch, out_ch, heads, True, layers_per_block))
+            else:
+                self.down_blocks.append(DownBlock2D(in_ch, out_ch, False, layers_per_block))
+        self.mid_block = UNetMidBlock2DCrossAttn(boc[-1], heads)
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(boc))
+        out_ch = rev[0]
+        self.num_upsamplers = 0
+        for i in range(len(rev)):
+            prev = out_ch
+            out_ch = rev[i]
+            in_ch = rev[min(i + 1, len(rev) - 1)]
+            final = i == len(rev) - 1
+            if not final:
+                self.num_upsamplers += 1
+            if i == 0:
+                self.up_blocks.append(UpBlock2D(in_ch, prev, out_ch, not final, layers_per_block + 1))
+            else:
+                self.up_blocks.append(CrossAttnUpBlock2D(in_ch, prev, out_ch, heads, not final, layers_per_block + 1))
+        self.conv_norm_out = GroupNorm(32, boc[0], eps=1e-5)
+        self.conv_act = Identity()
+        self.conv_out = Conv2d(boc[0], out_channels, 3, padding=1)
+
+    # ---- peft-through-diffusers surface (mtmadise.py:115-147) ----
+    def add_adapter(self, adapter_config, adapter_name="default", generator=None):
+        targets = tuple(adapter_config.target_modules)
+        for name, module in list(self.named_modules()):
+            if isinstance(module, LoraLinear):
+                if name.endswith(targets):
+                    module.update_layer(adapter_name, adapter_config.r, adapter_config.lora_alpha, generator)
+                continue
+            if isinstance(module, Linear) and name.endswith(targets) and ".lora_" not in name \
+                    and not name.endswith("base_layer"):
+                parent_name, _, child = name.rpartition(".")
+                parent = self.get_submodule(parent_name)
+                wrapped = LoraLinear(module)
+                wrapped.update_layer(adapter_name, adapter_config.r, adapter_config.lora_alpha, generator)
+                if isinstance(parent, nn.ModuleList):
+                    parent[int(child)] = wrapped
+                else:
+                    setattr(parent, child, wrapped)
+
+    def set_adapter(self, names):
+        names = [names] if isinstance(names, str) else list(names)
+        for m in self.modules():
+            if isinstance(m, LoraLinear):
+                m._active_adapter = names
+
+    # ---- time rows of all resnets in one GEMM ----
+    def _resnets(self):
+        out = []
+        for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks):
+            out.extend(blk.resnets)
+        return out
+
+    def _time_rows(self, emb):
+        """emb: [B, 1280] (compute dtype).  Returns one f32 [B, C_r] view per resnet:
+        time_emb_proj_r(silu(emb)) for every ResnetBlock2D, from ONE GEMM over the stacked weights."""
+        resnets = self._resnets()
+        cache = self.__dict__.setdefault("_temb_cache", {})
+        ver = tuple((r.time_emb_proj.weight._version, r.time_emb_proj.weight.data_ptr(),
+                     r.time_emb_proj.bias._version) for r in resnets)
+        hit = cache.get(emb.dtype)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                W = torch.cat([r.time_emb_proj.weight.detach().float() for r in resnets], 0)
+                b = torch.cat([r.time_emb_proj.bias.detach().float() for r in resnets], 0).contiguous()
+                Wp = packing.pack_linear_weight(W, emb.dtype, ops.k_tile(emb.dtype))
+            hit = (ver, Wp, b)
+            cache[emb.dtype] = hit
+        _, Wp, b = hit
+        rows = ops.rows_to_f32(ops.linear(ops.silu(emb), Wp, bias=b))
+        out, off = {}, 0
+        for r in resnets:
+            n = r.time_emb_proj.out_features
+            out[id(r)] = rows[:, off:off + n]
+            off += n
+        return out
+
+    def forward(self, sample, timesteps, ctx, Lk, cond_emb=None, unet_block_indices=(), unet_block_indices_type="after"):
+        """sample: Tok (latents, channels padded to the K-tile); timesteps: int64 [B];
+        ctx: [B*Lk, 768] tokens; cond_emb: f32 [B, 1280] or None ("emb += res_time_embedding").
+        Returns (sample Tok [.., 4], taps list[Tok]) with the reference's tap semantics
+        (ldm_diffusers.py:372-375,389-392,411-414,442-445)."""
+        dtype = sample.t.dtype
+        freqs = self.__dict__.get("_freqs")
+        if freqs is None or freqs.device != sample.t.device:
+            freqs = ops.timestep_freqs(self.block_out_channels[0], sample.t.device)
+            self.__dict__["_freqs"] = freqs
+        t_emb = ops.timestep_embedding(timesteps, freqs, dtype)
+        # emb = time_embedding(t_emb); emb += res_time_embedding (ldm_diffusers.py:505-509): the add is
+        # the residual input of linear_2's epilogue
+        res = None if cond_emb is None else ops.cast_from_f32(cond_emb.contiguous(), dtype)
+        emb = self.time_embedding(t_emb, residual=res)
+        rows = self._time_rows(emb)
+
+        h = self.conv_in(sample)
+        skips = [h]
+        for blk in self.down_blocks:
+            for i, resnet in enumerate(blk.resnets):
+                h = resnet(h, rows[id(resnet)])
+                if blk.has_cross_attention:
+                    h = blk.attentions[i](h, ctx, Lk)
+                skips.append(h)
+            if blk.downsamplers is not None:
+                for d in blk.downsamplers:
+                    h = d(h)
+                skips.append(h)
+
+        mb = self.mid_block
+        h = mb.resnets[0](h, rows[id(mb.resnets[0])])
+        for attn, resnet in zip(mb.attentions, mb.resnets[1:]):
+            h = attn(h, ctx, Lk)
+            h = resnet(h, rows[id(resnet)])
+
+        taps, idx = [], 0
+        for blk in self.up_blocks:
+            for i, resnet in enumerate(blk.resnets):
+                skip = skips.pop()
+                if unet_block_indices_type == "in":
+                    if idx in unet_block_indices:
+                        taps.append((h, skip))  # post-concat tap: two sources, joined at hand-over
+                    idx += 1
+                h = resnet(h, rows[id(resnet)], skip=skip)
+                if blk.has_cross_attention:
+                    h = blk.attentions[i](h, ctx, Lk)
+                if unet_block_indices_type == "after":
+                    if idx in unet_block_indices:
+                        taps.append(h)
+                    idx += 1
+            if blk.upsamplers is not None:
+                for u in blk.upsamplers:
+                    h = u(h)
+        assert len(taps) == len(unet_block_indices)
+        h = self.conv_norm_out(h, silu=True)
+        return self.conv_out(h), taps

@@ -1,0 +1,196 @@
+"""SD-v1-4 ``AutoencoderKL`` on the HIP path (diffusers 0.25 module/parameter names).
+
+Replaces the diffusers modules the reference drives from
+modeling/meta_arch/ldm_diffusers.py:283-311 (``vae_encoder``) and :314-346 (``vae_decoder``).
+Parameter tree == diffusers' AutoencoderKL (83,653,863 parameters).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+from .nn import Tok, Conv2d, Linear, GroupNorm, Identity, _Packed
+from .sd_unet import ResnetBlock2D, Downsample2D, Upsample2D, _FusedProj
+
+
+class VaeAttention(nn.Module):
+    """Single-head spatial attention of the VAE mid block: GroupNorm -> q,k,v (with bias) ->
+    softmax(QK^T/sqrt(C)) V -> to_out -> + input."""
+
+    def __init__(self, channels, eps=1e-6):
+        super().__init__()
+        self.channels = channels
+        self.group_norm = GroupNorm(32, channels, eps=eps)
+        self.to_q = Linear(channels, channels)
+        self.to_k = Linear(channels, channels)
+        self.to_v = Linear(channels, channels)
+        self.to_out = nn.ModuleList([Linear(channels, channels), Identity()])
+
+    def forward(self, x):
+        C = self.channels
+        f_qkv = self.__dict__.get("_f_qkv")
+        if f_qkv is None or f_qkv._layers[0] is not self.to_q:
+            f_qkv = _FusedProj([self.to_q, self.to_k, self.to_v])
+            self.__dict__["_f_qkv"] = f_qkv
+        h = self.group_norm(x)
+        qkv = f_qkv(h.t)
+        o = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, 1, x.HW, x.HW, C, C ** -0.5)
+        return x.like(self.to_out[0](o, residual=x.t))
+
+
+class UNetMidBlock2D(nn.Module):
+    def __init__(self, channels, eps=1e-6):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(channels, channels, temb_channels=None, eps=eps),
+                                      ResnetBlock2D(channels, channels, temb_channels=None, eps=eps)])
+        self.attentions = nn.ModuleList([VaeAttention(channels, eps)])
+
+    def forward(self, x):
+        x = self.resnets[0](x)
+        for attn, resnet in zip(self.attentions, self.resnets[1:]):
+            x = resnet(attn(x))
+        return x
+
+
+class DownEncoderBlock2D(nn.Module):
+    def __init__(self, in_channels, out_channels, add_downsample, num_layers=2):
+        super().__init__()
+        self.resnets = nn.ModuleList([
+            ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels, temb_channels=None, eps=1e-6)
+            for i in range(num_layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels, padding=0)]) if add_downsample else None
+
+
+class UpDecoderBlock2D(nn.Module):
+    def __init__(self, in_channels, out_channels, add_upsample, num_layers=3):
+        super().__init__()
+        self.resnets = nn.ModuleList([
+            ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels, temb_channels=None, eps=1e-6)
+            for i in range(num_layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_channels=3, out_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2):
+        super().__init__()
+        boc = tuple(block_out_channels)
+        self.conv_in = Conv2d(in_channels, boc[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        out_ch = boc[0]
+        for i, ch in enumerate(boc):
+            in_ch, out_ch = out_ch, ch
+            self.down_blocks.append(DownEncoderBlock2D(in_ch, out_ch, i != len(boc) - 1, layers_per_block))
+        self.mid_block = UNetMidBlock2D(boc[-1])
+        self.conv_norm_out = GroupNorm(32, boc[-1], eps=1e-6)
+        self.conv_act = Identity()
+        self.conv_out = Conv2d(boc[-1], 2 * out_channels, 3, padding=1)
+
+
+class Decoder(nn.Module):
+    def __init__(self, in_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2):
+        super().__init__()
+        boc = tuple(block_out_channels)
+        self.conv_in = Conv2d(in_channels, boc[-1], 3, padding=1)
+        self.mid_block = UNetMidBlock2D(boc[-1])
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(boc))
+        out_ch = rev[0]
+        for i, ch in enumerate(rev):
+            prev, out_ch = out_ch, ch
+            self.up_blocks.append(UpDecoderBlock2D(prev, out_ch, i != len(rev) - 1, layers_per_block + 1))
+        self.conv_norm_out = GroupNorm(32, boc[0], eps=1e-6)
+        self.conv_act = Identity()
+        self.conv_out = Conv2d(boc[0], out_channels, 3, padding=1)
+
+
+class _Config:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class AutoencoderKL(_Packed):
+    def __init__(self, block_out_channels=(128, 256, 512, 512), latent_channels=4):
+        super().__init__()
+        self.config = _Config(scaling_factor=0.18215, latent_channels=latent_channels)
+        self.latent_channels = latent_channels
+        self.encoder = Encoder(3, latent_channels, block_out_channels)
+        self.decoder = Decoder(latent_channels, 3, block_out_channels)
+        self.quant_conv = Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+        self.post_quant_conv = Conv2d(latent_channels, latent_channels, 1)
+
+    def _versions(self):
+        ps = [self.encoder.conv_out.weight, self.encoder.conv_out.bias, self.quant_conv.weight, self.quant_conv.bias,
+              self.decoder.conv_in.weight, self.decoder.conv_in.bias, self.post_quant_conv.weight,
+              self.post_quant_conv.bias]
+        return tuple((p._version, p.data_ptr()) for p in ps)
+
+    # ---- encoder: vae_encoder (ldm_diffusers.py:283-311) up to ``moments`` ----
+    def encode_moments(self, x, encoder_block_indices=()):
+        """x: Tok of the normalised image (channels padded to the K-tile).  Returns
+        (moments Tok [.., 8] = quant_conv(encoder(x)), taps list[Tok]).  quant_conv (1x1, 8->8) is
+        folded into encoder.conv_out's weights: W' = Wq W, b' = Wq b + bq (exact composition)."""
+        enc = self.encoder
+        taps, index = [], 0
+        h = enc.conv_in(x)
+        for blk in enc.down_blocks:
+            for resnet in blk.resnets:
+                h = resnet(h)
+                index += 1
+                if index in encoder_block_indices:
+                    taps.append(h)
+            if blk.downsamplers is not None:
+                for d in blk.downsamplers:
+                    h = d(h)
+        h = enc.mid_block(h)
+        h = enc.conv_norm_out(h, silu=True)
+        dtype = h.t.dtype
+
+        def build():
+            W = enc.conv_out.weight.detach().double()            # [8, 512, 3, 3]
+            b = enc.conv_out.bias.detach().double()
+            Wq = self.quant_conv.weight.detach().double()[:, :, 0, 0]  # [8, 8]
+            bq = self.quant_conv.bias.detach().double()
+            Wf = torch.einsum("oc,cikl->oikl", Wq, W).float()
+            bf = (Wq @ b + bq).float().contiguous()
+            return packing.pack_conv_weight(Wf, dtype, ops.k_tile(dtype)), bf
+
+        wp, bp = self._cache_get((dtype, "enc_out"), build)
+        o = ops.conv2d(h.t, wp, h.B, h.H, h.W, N=wp.shape[0], KH=3, KW=3, pad_t=1, pad_l=1, bias=bp)
+        return h.like(o), taps
+
+    # ---- decoder: vae_decoder (ldm_diffusers.py:314-346) ----
+    def decode(self, z, decoder_block_indices=(), output_final=True):
+        """z: Tok of UNSCALED latents (channels padded to the K-tile; the 1/scaling_factor of :319 and the
+        1x1 post_quant_conv are folded into decoder.conv_in).  Returns (sample Tok [.., 4 (3 used)] or None, taps)."""
+        dec = self.decoder
+        dtype = z.t.dtype
+
+        def build():
+            W = dec.conv_in.weight.detach().double()                   # [512, 4, 3, 3]
+            Wp_ = self.post_quant_conv.weight.detach().double()[:, :, 0, 0]  # [4, 4]
+            bp_ = self.post_quant_conv.bias.detach().double()
+            s = 1.0 / self.config.scaling_factor
+            # conv_in(post_quant(z * s)) = sum_c W[o,c] (sum_i Wp[c,i] s z_i + bp[c]); the bp term is NOT a
+            # constant bias under zero padding, so post_quant's bias is kept exact by an extra input channel
+            # that carries 1 inside the image (channel index 4 of the padded latent tensor).
+            Wf = torch.einsum("ockl,ci->oikl", W, Wp_) * s
+            Wb = torch.einsum("ockl,c->okl", W, bp_)[:, None]
+            Wf = torch.cat([Wf, Wb], dim=1).float()                    # [512, 5, 3, 3]
+            return packing.pack_conv_weight(Wf, dtype, ops.k_tile(dtype)), dec.conv_in.bias.detach().float().contiguous()
+
+        wp, bp = self._cache_get((dtype, "dec_in"), build)
+        h = ops.conv2d(z.t, wp, z.B, z.H, z.W, N=wp.shape[0], KH=3, KW=3, pad_t=1, pad_l=1, bias=bp)
+        h = dec.mid_block(z.like(h))
+        taps, index = [], 0
+        for blk in dec.up_blocks:
+            for resnet in blk.resnets:
+                if index in decoder_block_indices:
+                    taps.append(h)
+                index += 1
+                h = resnet(h)
+            if blk.upsamplers is not None:
+                for u in blk.upsamplers:
+                    h = u(h)
+        if not output_final:
+            return None, taps
+        h = dec.conv_norm_out(h, silu=True)
+        return dec.conv_out(h), taps

@@ -1,0 +1,110 @@
+"""Generates the committed golden vectors of the hot path.  RUNS ONLY IN THE BUILD CONTAINER (needs
+/root/reference): the reference's OWN functions ``vae_encoder`` / ``add_noise`` / ``diffusion_unet``
+(modeling/meta_arch/ldm_diffusers.py:283-311,349-360,454-616), loaded by path, drive the CPU fp32
+oracle modules (oracle/sd_modules.py) filled with seeded synthetic parameters (madm_amd/weights.py).
+Inputs are regenerated from seeds by the tests (``make_inputs``); only outputs are stored.
+
+    python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import sd_modules, ref_driver  # noqa: E402
+from madm_amd import weights  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WEIGHT_SEED = 0
+
+CASES = {
+    # name: (B, H, W, timestep, cond_emb_scale, lora, tap_type)
+    "small_t0": dict(B=2, H=64, W=64, t=0, cond_scale=0.0, lora=False),
+    "small_t60": dict(B=2, H=64, W=64, t=60, cond_scale=0.02, lora=False),
+    "small_lora": dict(B=2, H=64, W=64, t=60, cond_scale=0.02, lora=True),
+    "rect_t0": dict(B=1, H=64, W=128, t=0, cond_scale=0.02, lora=False),
+    "full_t0": dict(B=1, H=512, W=512, t=0, cond_scale=0.0, lora=False),
+}
+CH_STRIDE_FULL = 16  # the 512x512 case stores every 16th channel of each tap
+
+
+def make_inputs(B, H, W, t, cond_scale):
+    """Synthetic inputs of SURVEY.md 8(d): uniform images, 0.02*randn prompt/time conditioning."""
+    images = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(1234))
+    cond = 0.02 * torch.randn((1, 77, 768), generator=torch.Generator().manual_seed(1235))
+    cond_inputs = cond.repeat_interleave(B, dim=0)
+    cond_emb = cond_scale * torch.randn((B, 1, 1280), generator=torch.Generator().manual_seed(1236))
+    timesteps = torch.full((B,), t, dtype=torch.int64)
+    shared_noise = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(42))
+    return images, cond_inputs, cond_emb, timesteps, shared_noise
+
+
+def build_oracle(lora=False, seed=WEIGHT_SEED):
+    vae = sd_modules.AutoencoderKL()
+    unet = sd_modules.UNet2DConditionModel()
+    weights.synth_init_(vae, seed, "vae.")
+    weights.synth_init_(unet, seed, "unet.")
+    if lora:
+        add_lora(unet, sd_modules.LoraConfig, seed)
+    return vae.eval(), unet.eval()
+
+
+def add_lora(unet, LoraConfig, seed=WEIGHT_SEED):
+    """Two adapters as `--lora_configs default_r8_a8 Depth_r8_a16` would create (mtmadise.py:48-54,115-127);
+    'Depth' active.  A and B get seeded non-trivial values (B = 0 would make the adapter a no-op)."""
+    unet.add_adapter(LoraConfig(r=8, lora_alpha=8), "default")
+    unet.add_adapter(LoraConfig(r=8, lora_alpha=16), "Depth")
+    unet.set_adapter(["default", "Depth"])
+    with torch.no_grad():
+        for name, p in unet.named_parameters():
+            if ".lora_" in name:
+                g = weights._gen(seed, "unet." + name)
+                p.copy_(torch.randn(p.shape, generator=g) / (p.shape[1] ** 0.5))
+    for m in unet.modules():
+        if hasattr(m, "_active_adapter"):
+            m._active_adapter = ["Depth"]
+
+
+def run_reference(ref, vae, unet, sched, case):
+    images, cond_inputs, cond_emb, timesteps, shared_noise = make_inputs(case["B"], case["H"], case["W"], case["t"],
+                                                                         case["cond_scale"])
+    with torch.no_grad():
+        x = (images - 0.5) / 0.5   # LdmDiffusers.forward :145-146
+        latents, _ = ref.vae_encoder(vae=vae, images=x, encoder_block_indices=[])
+        noisy = ref.add_noise(noise_scheduler=sched, latents=latents, timesteps=timesteps, shared_noise=shared_noise)
+        out, feats = ref.diffusion_unet(unet=unet, sample=noisy, timestep=timesteps, encoder_hidden_states=cond_inputs,
+                                        res_time_embedding=cond_emb.clone(), unet_block_indices=[5, 8, 11],
+                                        unet_block_indices_type='after')
+    return latents, noisy, out.sample, feats
+
+
+def main():
+    assert ref_driver.available(), "needs /root/reference"
+    ref = ref_driver.load()
+    sched = sd_modules.DDPMScheduler()
+    torch.set_num_threads(os.cpu_count())
+    models = {}
+    for name, case in CASES.items():
+        key = case["lora"]
+        if key not in models:
+            models[key] = build_oracle(lora=key)
+        vae, unet = models[key]
+        t0 = time.time()
+        latents, noisy, sample, feats = run_reference(ref, vae, unet, sched, case)
+        stride = CH_STRIDE_FULL if name.startswith("full") else 1
+        out = {"latents": latents.numpy(), "noisy": noisy.numpy(), "sample": sample.numpy()}
+        for i, f in enumerate(feats):
+            out[f"tap{i}"] = f[:, ::stride].contiguous().numpy()
+            out[f"tap{i}_stats"] = np.array([f.mean().item(), f.std().item(), f.abs().max().item()], dtype=np.float64)
+            out[f"tap{i}_shape"] = np.array(f.shape, dtype=np.int64)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(f"{name}: {time.time() - t0:.1f}s", {k: v.shape for k, v in out.items() if not k.endswith('_stats')})
+
+
+if __name__ == "__main__":
+    main()

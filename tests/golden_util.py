@@ -1,0 +1,53 @@
+"""Shared by the CPU and GPU parity tests: seeded inputs of the golden cases and fixture loading."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+WEIGHT_SEED = 0
+CH_STRIDE_FULL = 16
+
+CASES = {
+    "small_t0": dict(B=2, H=64, W=64, t=0, cond_scale=0.0, lora=False),
+    "small_t60": dict(B=2, H=64, W=64, t=60, cond_scale=0.02, lora=False),
+    "small_lora": dict(B=2, H=64, W=64, t=60, cond_scale=0.02, lora=True),
+    "rect_t0": dict(B=1, H=64, W=128, t=0, cond_scale=0.02, lora=False),
+    "full_t0": dict(B=1, H=512, W=512, t=0, cond_scale=0.0, lora=False),
+}
+
+
+def make_inputs(B, H, W, t, cond_scale, **_):
+    images = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(1234))
+    cond = 0.02 * torch.randn((1, 77, 768), generator=torch.Generator().manual_seed(1235))
+    cond_inputs = cond.repeat_interleave(B, dim=0)
+    cond_emb = cond_scale * torch.randn((B, 1, 1280), generator=torch.Generator().manual_seed(1236))
+    timesteps = torch.full((B,), t, dtype=torch.int64)
+    shared_noise = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(42))
+    return images, cond_inputs, cond_emb, timesteps, shared_noise
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def add_lora(unet, LoraConfig, seed=WEIGHT_SEED):
+    """Same adapters / values as tests/golden/gen_golden.py::add_lora, for any module tree with the
+    peft-shaped names (oracle or madm_amd)."""
+    from madm_amd import weights
+    unet.add_adapter(LoraConfig(r=8, lora_alpha=8), "default")
+    unet.add_adapter(LoraConfig(r=8, lora_alpha=16), "Depth")
+    unet.set_adapter(["default", "Depth"])
+    with torch.no_grad():
+        for name, p in unet.named_parameters():
+            if ".lora_" in name:
+                g = weights._gen(seed, "unet." + name)
+                p.copy_((torch.randn(p.shape, generator=g) / (p.shape[1] ** 0.5)).to(p.device))
+    for m in unet.modules():
+        if hasattr(m, "_active_adapter"):
+            m._active_adapter = ["Depth"]
+
+
+def tap_subset(name, t):
+    return t[:, ::CH_STRIDE_FULL] if name.startswith("full") else t

@@ -208,6 +208,8 @@ def test_glue_kernels(cuda, dtype):
     assert abs(mmc[0].item() - ref.min().item()) < 1e-6 and abs(mmc[1].item() - ref.max().item()) < 1e-6
     # nhwc -> nchw
     back = ops.nhwc_to_nchw(t, 2, 3, 16, 24).cpu()
+    both = ops.nhwc_to_nchw([t, t], 2, [3, 2], 16, 24).cpu()
+    assert torch.equal(both[:, :3], back) and torch.equal(both[:, 3:], back[:, :2])
     assert rel_err(back, got[:, :3])[0] == 0.0
     # timestep embedding
     ts = torch.tensor([0, 60, 999], dtype=torch.int64)
@@ -215,7 +217,7 @@ def test_glue_kernels(cuda, dtype):
     freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
     arg = ts[:, None].float() * freqs[None]
     ref = torch.cat([torch.cos(arg), torch.sin(arg)], -1)
-    emb = ops.timestep_embedding(ts.cuda(), 320, dtype).float().cpu()
+    emb = ops.timestep_embedding(ts.cuda(), ops.timestep_freqs(320, "cuda"), dtype).float().cpu()
     assert (emb - ref).abs().max().item() < (2e-5 if dtype == torch.float32 else 5e-3)
     # silu / rows_to_f32
     x = _q(_gen((2, 1280), 1), dtype)

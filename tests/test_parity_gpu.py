@@ -1,0 +1,136 @@
+"""End-to-end parity of the HIP path (through the C ABI) with the committed golden vectors that the
+reference's own functions produced (tests/golden/gen_golden.py), and with the live CPU oracle.
+
+Tolerances (stated per north_star): exact-f32 mode: 1e-3 relative to the tensor's max magnitude
+(observed ~1e-5); bf16 mode: relative L2 <= 4e-2 per tensor -- bf16 storage rounds every activation
+to 8 bits of mantissa over ~60 layers, the reference itself runs fp16 autocast."""
+import pytest
+import torch
+
+from golden_util import CASES, make_inputs, load_golden, add_lora, tap_subset
+from util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-3
+BF16_L2_TOL = 4e-2
+
+
+class _LoraConfig:
+    def __init__(self, r, lora_alpha):
+        self.r, self.lora_alpha = r, lora_alpha
+        self.init_lora_weights = "gaussian"
+        self.target_modules = ["to_k", "to_q", "to_v", "to_out.0"]
+
+
+@pytest.fixture(scope="module")
+def extractor(cuda):
+    from madm_amd.ldm_rocm import LdmRocm
+    m = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=[],
+                input_range='-1+1', unet_block_indices_type='after', finetune_unet='all',
+                compute_dtype=torch.float32, weights='synthetic', seed=0)
+    return m
+
+
+def _run(m, case, dtype):
+    images, cond_inputs, cond_emb, timesteps, _ = make_inputs(**case)
+    m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = dtype
+    t = case["t"]
+    feats = m({"img": images.cuda(), "cond_inputs": cond_inputs.cuda(), "cond_emb": cond_emb.cuda(),
+               "timestep": (t, t + 1)}, "rgb")
+    torch.cuda.synchronize()
+    sample = m.last_sample.nchw(4).cpu()
+    return m.last_latents.cpu(), sample, [f.cpu() for f in feats]
+
+
+def _compare(name, got, gold, dtype):
+    lat, sample, feats = got
+    report = []
+    pairs = [("latents", lat, gold["latents"]), ("sample", sample, gold["sample"])]
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == tuple(gold[f"tap{i}_shape"].tolist()), (f.shape, gold[f"tap{i}_shape"])
+        pairs.append((f"tap{i}", tap_subset(name, f), gold[f"tap{i}"]))
+    ok = True
+    for key, a, b in pairs:
+        e, l2 = rel_err(a, b)
+        report.append(f"{key}: max {e:.2e} l2 {l2:.2e}")
+        ok &= (e < F32_TOL) if dtype == torch.float32 else (l2 < BF16_L2_TOL)
+    print(name, dtype, "; ".join(report))
+    assert ok, f"{name} {dtype}: " + "; ".join(report)
+
+
+@pytest.mark.parametrize("name", ["small_t0", "small_t60", "rect_t0", "full_t0"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_golden(extractor, name, dtype):
+    _compare(name, _run(extractor, CASES[name], dtype), load_golden(name), dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_golden_lora(cuda, dtype):
+    """peft-style LoRA (mtmadise.py:115-147): two adapters registered, 'Depth' active."""
+    from madm_amd.ldm_rocm import LdmRocm
+    m = LdmRocm("", [], [5, 8, 11], [], input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
+                compute_dtype=dtype, weights='synthetic', seed=0)
+    add_lora(m.unet, _LoraConfig)
+    names = [n for n, _ in m.unet.named_parameters() if "lora" in n]
+    assert len(names) == 128 * 2 * 2 and all(("default" in n) or ("Depth" in n) for n in names)
+    _compare("small_lora", _run(m, CASES["small_lora"], dtype), load_golden("small_lora"), dtype)
+    # switching the adapter changes the result; disabling restores the base model
+    base = load_golden("small_t60")
+    for mod in m.unet.modules():
+        if hasattr(mod, "_active_adapter"):
+            mod._active_adapter = []
+    _compare("small_t60", _run(m, CASES["small_t60"], dtype), base, dtype)
+
+
+def test_batch_invariance_and_determinism(extractor):
+    """Size-independent properties at the full 512x512 size in bf16: images are independent units
+    (GroupNorm/LayerNorm are per-sample), so a batch of two equal images gives two equal outputs that
+    equal the single-image result bit for bit, and repeated runs are bit-identical."""
+    case = dict(CASES["full_t0"])
+    images, cond_inputs, cond_emb, _, _ = make_inputs(**case)
+    m = extractor
+    m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = torch.bfloat16
+
+    def run(B):
+        feats = m({"img": images.repeat(B, 1, 1, 1).cuda(), "cond_inputs": cond_inputs.repeat(B, 1, 1).cuda(),
+                   "cond_emb": cond_emb.repeat(B, 1, 1).cuda()}, "rgb")
+        torch.cuda.synchronize()
+        return [f.cpu() for f in feats]
+
+    one, two, again = run(1), run(2), run(2)
+    for a, b, c in zip(one, two, again):
+        assert torch.equal(b[0:1], b[1:2]), "batch elements differ"
+        assert torch.equal(b, c), "not deterministic"
+        e, l2 = rel_err(b[0:1], a)
+        assert l2 < 1e-2, f"B=2 vs B=1: {e:.2e} {l2:.2e}"   # tile/split-K choices may differ with M
+
+
+def test_helper_functions_match_reference_signatures(extractor):
+    """vae_encoder / add_noise / diffusion_unet keep the reference's call signatures
+    (ldm_diffusers.py:283,349,454) and reproduce the golden intermediates when chained by hand."""
+    from madm_amd import ldm_rocm
+    m = extractor
+    m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = torch.float32
+    case = CASES["small_t60"]
+    gold = load_golden("small_t60")
+    images, cond_inputs, cond_emb, timesteps, shared_noise = make_inputs(**case)
+    x = ((images - 0.5) / 0.5).cuda()
+    latents, feats = ldm_rocm.vae_encoder(vae=m.vae, images=x, encoder_block_indices=[])
+    assert feats == [] and rel_err(latents.cpu(), gold["latents"])[0] < F32_TOL
+    noisy = ldm_rocm.add_noise(noise_scheduler=m.noise_scheduler, latents=latents, timesteps=timesteps.cuda(),
+                               shared_noise=m.shared_noise)
+    assert rel_err(noisy.cpu(), gold["noisy"])[0] < F32_TOL
+    out, taps = ldm_rocm.diffusion_unet(unet=m.unet, sample=noisy, timestep=timesteps.cuda(),
+                                        encoder_hidden_states=cond_inputs.cuda(), res_time_embedding=cond_emb.cuda(),
+                                        unet_block_indices=[5, 8, 11], unet_block_indices_type='after')
+    assert rel_err(out.sample.cpu(), gold["sample"])[0] < F32_TOL
+    for i, t in enumerate(taps):
+        assert rel_err(t.cpu(), gold[f"tap{i}"])[0] < F32_TOL
+    # encoder taps are 1-based resnet counts (:291-293); 'in' taps are post-concat (:372-375)
+    _, etaps = ldm_rocm.vae_encoder(vae=m.vae, images=x, encoder_block_indices=[5])
+    assert tuple(etaps[0].shape) == (2, 512, 16, 16)
+    _, itaps = ldm_rocm.diffusion_unet(unet=m.unet, sample=noisy, timestep=timesteps.cuda(),
+                                       encoder_hidden_states=cond_inputs.cuda(), res_time_embedding=None,
+                                       unet_block_indices=[0, 5, 11], unet_block_indices_type='in')
+    assert [t.shape[1] for t in itaps] == [2560, 1920, 640]
