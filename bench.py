@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- UNet feature-extract images/sec @512x512, bs=2/GPU (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
+VAE encode -> add_noise -> UNet (LoRA off, shipped configs) -> taps [1280@16, 640@32, 320@64] handed
+over as NCHW f32, i.e. LdmRocm.forward (== LdmDiffusers.forward, ldm_diffusers.py:143-217).  The
+forward is captured once into a hipGraph (torch.cuda.CUDAGraph around the C-ABI launches) and
+replayed; timing brackets exactly K replays with barrier + synchronize, max over ranks.
+
+Multi-GPU: the path shards by image with no exchange step ("replicas only"): every
+rank runs its own bs=2 batch; RCCL is used only for the barrier and the max-over-ranks of the time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_FLOP_PER_IMAGE = 1.91993e12   # VAE-enc 1116.66 + UNet 803.27 GFLOP
+PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level table)
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU (BASELINE: 2)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--lora", action="store_true", help="enable one r=8 LoRA adapter (north_star variant)")
+    return ap.parse_args()
+
+
+def make_inputs(B, size, device):
+    img = torch.rand((B, 3, size, size), generator=torch.Generator().manual_seed(1234))
+    cond = 0.02 * torch.randn((1, 77, 768), generator=torch.Generator().manual_seed(1235))
+    return {"img": img.to(device), "cond_inputs": cond.repeat_interleave(B, 0).to(device),
+            "cond_emb": torch.zeros((B, 1, 1280), device=device)}
+
+
+def kernel_profile(model, inputs):
+    """Eager pass with HIP events around every MFMA-kernel launch (events recorded on the launch
+    stream).  Returns {kernel: (launches, total_ms, algorithmic_flops)}."""
+    from madm_amd import ops
+    for _ in range(2):
+        model(inputs, "rgb")
+    torch.cuda.synchronize()
+    ops.PROFILE = []
+    try:
+        model(inputs, "rgb")
+        torch.cuda.synchronize()
+        rec = ops.PROFILE
+    finally:
+        ops.PROFILE = None
+    agg = {}
+    for name, flops, e0, e1 in rec:
+        n, ms, fl = agg.get(name, (0, 0.0, 0.0))
+        agg[name] = (n + 1, ms + e0.elapsed_time(e1), fl + flops)
+    return agg
+
+
+def cpu_baseline(size):
+    """The CPU oracle (oracle/, a restatement -> kind "port") on the host cores: 1 image, 1 warm-up
+    + 2 timed runs of the same VAE-enc -> add_noise -> UNet graph in fp32."""
+    from oracle import sd_modules, ldm_path
+    from madm_amd import weights
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    vae = sd_modules.AutoencoderKL().eval()
+    unet = sd_modules.UNet2DConditionModel().eval()
+    weights.synth_init_(vae, 0, "vae.")
+    weights.synth_init_(unet, 0, "unet.")
+    sched = sd_modules.DDPMScheduler()
+    img = torch.rand((1, 3, size, size), generator=torch.Generator().manual_seed(1234))
+    cond = 0.02 * torch.randn((1, 77, 768), generator=torch.Generator().manual_seed(1235))
+    noise = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(42))
+    ts = torch.zeros(1, dtype=torch.int64)
+    times = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        ldm_path.ldm_forward(vae, unet, sched, noise, img, cond, torch.zeros(1, 1, 1280), timesteps=ts)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[0]
+    return {"value": round(1.0 / t, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 image {size}x{size}, fp32 torch-CPU oracle, best of 2 after 1 warm-up "
+                      f"({t:.2f} s/image = {ALG_FLOP_PER_IMAGE / t / 1e9:.0f} GFLOP/s)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from madm_amd.ldm_rocm import LdmRocm
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=[],
+                    input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
+                    compute_dtype=dtype, weights='synthetic', seed=0, device=device)
+    if args.lora:
+        from types import SimpleNamespace
+        from madm_amd import weights
+        model.unet.add_adapter(SimpleNamespace(r=8, lora_alpha=8, target_modules=["to_k", "to_q", "to_v", "to_out.0"]),
+                               "Depth")
+        model.unet.set_adapter(["Depth"])
+        weights.randomize_lora_B_(model.unet)
+    inputs = make_inputs(args.batch, args.size, device)
+
+    # eager warm-up: packs weights, sizes workspaces, checks the input range once
+    model(inputs, "rgb")
+    torch.cuda.synchronize()
+    model.check_input_range = False
+
+    prof = None
+    if rank == 0 and not args.no_kernel_profile:
+        prof = kernel_profile(model, inputs)
+
+    if args.no_graph:
+        def step():
+            return model(inputs, "rgb")
+    else:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(inputs, "rgb")
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph):
+            static_out = model(inputs, "rgb")
+
+        def step():
+            graph.replay()
+            return static_out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        value = images / elapsed
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        out = {
+            "metric": "UNet feature-extract images/sec @512x512 bs=2/GPU",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: SD-v1-4 VAE-encode + UNet single-timestep feature extractor "
+                                   f"(taps 5,8,11 'after'), {args.batch}x3x{args.size}x{args.size} per GPU, t=0, "
+                                   "LoRA " + ("r=8 on" if args.lora else "off (shipped configs)") +
+                                   ", seeded synthetic weights",
+                       "global_batch": args.batch * world, "parallelism": f"replicas x{world} (no collectives)",
+                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+            "device_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 4),
+            "whole_path_roofline_frac": round(value / world * ALG_FLOP_PER_IMAGE / (peak * 1e12), 4),
+        }
+        if prof:
+            dom = max(prof.items(), key=lambda kv: kv[1][1])
+            name, (n, ms, fl) = dom
+            achieved = fl / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
+                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                               "launches_per_step": n, "kernel_ms_per_step": round(ms, 4)}
+            out["kernels"] = {k: {"launches": v[0], "ms": round(v[1], 4),
+                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None}
+                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

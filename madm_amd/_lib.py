@@ -64,6 +64,7 @@ SYMBOLS = [
     ("madm_last_error", ctypes.c_char_p, []),
     ("madm_conv2d_workspace_bytes", c_size_t, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_suggest_splitk", c_int, [ctypes.POINTER(Conv2dArgs)]),
+    ("madm_conv2d_pick_tile", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_fwd", c_int, [ctypes.POINTER(Conv2dArgs), c_void_p]),
     ("madm_debug_set_conv_tile", None, [c_int]),
     ("madm_groupnorm_stats", c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -302,6 +302,11 @@ size_t madm_conv2d_workspace_bytes(const madm_conv2d_args* a) {
     return (size_t)a->splitk * M * (size_t)a->N * sizeof(float);
 }
 
+int madm_conv2d_pick_tile(const madm_conv2d_args* a) {
+    if (!a) return 0;
+    return pick_tile(a->B * a->OH * a->OW, a->N);
+}
+
 int madm_conv2d_suggest_splitk(const madm_conv2d_args* a) {
     if (!a) return 1;
     const int bke = (a->dtype == MADM_BF16) ? 64 : 32;

@@ -225,6 +225,7 @@ class LdmRocm(nn.Module):
         self.register_buffer("shared_noise", torch.randn(1, self.vae.latent_channels, *self.latent_image_size,
                                                          generator=rng).detach())
         self.register_buffer("uncond_inputs", self._get_uncond_inputs('').detach())
+        self.register_buffer("_minmax_init", torch.tensor([float("inf"), float("-inf")]), persistent=False)
         self.vae_decoder_loss = vae_decoder_loss
         self.final_fuse_vae_decoder_feat = final_fuse_vae_decoder_feat
         if vae_decoder_loss or len(decoder_block_indices) != 0:
@@ -284,7 +285,10 @@ class LdmRocm(nn.Module):
         dev = images.device
         B, _, H, W = images.shape
         mean, std = (self.input_mean, self.input_std) if self.input_range == '-1+1' else (0.0, 1.0)
-        minmax = torch.tensor([float("inf"), float("-inf")], device=dev) if self.input_range == '-1+1' else None
+        minmax = None
+        if self.input_range == '-1+1':   # device-to-device reset: capture-safe (no host memcpy in the graph)
+            minmax = torch.empty(2, device=dev)
+            minmax.copy_(self._minmax_init)
         x = _img_tokens(images, dtype, mean, std, minmax)
         text_prompt = batched_inputs['cond_inputs']
         res_time_embedding = batched_inputs['cond_emb']

@@ -125,7 +125,8 @@ class Conv2d(_Packed):
         o = ops.conv2d(x.t, wp, x.B, x.H, x.W, N=self.n_pad, x2=None if x2 is None else x2.t,
                        KH=self.kernel_size, KW=self.kernel_size, stride=self.stride, pad_t=pad, pad_l=pad,
                        OH=OH, OW=OW, upsample=upsample, bias=b, rowvec=rowvec,
-                       residual=None if residual is None else residual.t, out=out)
+                       residual=None if residual is None else residual.t, out=out,
+                       alg_nk=(self.out_channels, self.kernel_size * self.kernel_size * self.in_channels))
         return Tok(o, x.B, OH, OW)
 
 

@@ -42,6 +42,29 @@ def _need_cuda(*ts):
 
 _workspaces = {}
 
+# Optional per-launch profiler used by bench.py: when PROFILE is a list, every MFMA-kernel launch
+# appends (kernel name, algorithmic FLOPs, start event, end event) recorded on the launch stream.
+PROFILE = None
+_TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64"}
+
+
+class _Prof:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+        return False
+
 
 def _workspace(nbytes, device):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
@@ -54,7 +77,7 @@ def _workspace(nbytes, device):
 
 def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
            upsample=False, bias=None, rowvec=None, residual=None, epilogue=EPI_NONE, out=None,
-           splitk=None):
+           splitk=None, alg_nk=None):
     """Implicit-GEMM conv / linear.  x1: [B*IH*IW, C1] dense; x2 optional second source (concat);
     w: packed [N, KH*KW*(C1+C2)]; returns out [B*OH*OW, N] (N/2 columns for GEGLU)."""
     _need_cuda(x1, w, x2, bias, rowvec, residual, out)
@@ -106,14 +129,20 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         ws = _workspace(nbytes, x1.device)
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
-    check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
+    if PROFILE is None:
+        check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
+    else:
+        an, ak = alg_nk if alg_nk is not None else (N, KH * KW * (C1 + C2))
+        name = _TILE_NAMES[lib.madm_conv2d_pick_tile(ctypes.byref(a))] + ("_f32" if x1.dtype == torch.float32 else "_bf16")
+        with _Prof(name, 2.0 * M * an * ak):
+            check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     return out
 
 
-def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=None, splitk=None):
+def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=None, splitk=None, alg_nk=None):
     """out = x @ w.T (+bias) (+residual); x: [M, K] dense, w: [N, K(+K2)]."""
     return conv2d(x, w, 1, x.shape[0], 1, N=w.shape[0], x2=x2, bias=bias, residual=residual,
-                  epilogue=epilogue, out=out, splitk=splitk)
+                  epilogue=epilogue, out=out, splitk=splitk, alg_nk=alg_nk)
 
 
 def groupnorm_stats(x, B, HW, G, sums, c_off=0, Ctot=None):
@@ -186,7 +215,8 @@ def attention(q, k, v, B, H, Lq, Lk, D, scale, out=None):
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.B, a.H, a.Lq, a.Lk, a.D = B, H, Lq, Lk, D
     a.scale = float(scale)
-    check(lib.madm_attention_fwd(ctypes.byref(a), _stream()), "madm_attention_fwd")
+    with _Prof(f"attn_d{D}" + ("_f32" if q.dtype == torch.float32 else "_bf16"), 4.0 * B * H * Lq * Lk * D):
+        check(lib.madm_attention_fwd(ctypes.byref(a), _stream()), "madm_attention_fwd")
     return out
 
 

@@ -22,26 +22,8 @@ from madm_amd import weights  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 WEIGHT_SEED = 0
 
-CASES = {
-    # name: (B, H, W, timestep, cond_emb_scale, lora, tap_type)
-    "small_t0": dict(B=2, H=64, W=64, t=0, cond_scale=0.0, lora=False),
-    "small_t60": dict(B=2, H=64, W=64, t=60, cond_scale=0.02, lora=False),
-    "small_lora": dict(B=2, H=64, W=64, t=60, cond_scale=0.02, lora=True),
-    "rect_t0": dict(B=1, H=64, W=128, t=0, cond_scale=0.02, lora=False),
-    "full_t0": dict(B=1, H=512, W=512, t=0, cond_scale=0.0, lora=False),
-}
-CH_STRIDE_FULL = 16  # the 512x512 case stores every 16th channel of each tap
-
-
-def make_inputs(B, H, W, t, cond_scale):
-    """Synthetic inputs of SURVEY.md 8(d): uniform images, 0.02*randn prompt/time conditioning."""
-    images = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(1234))
-    cond = 0.02 * torch.randn((1, 77, 768), generator=torch.Generator().manual_seed(1235))
-    cond_inputs = cond.repeat_interleave(B, dim=0)
-    cond_emb = cond_scale * torch.randn((B, 1, 1280), generator=torch.Generator().manual_seed(1236))
-    timesteps = torch.full((B,), t, dtype=torch.int64)
-    shared_noise = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(42))
-    return images, cond_inputs, cond_emb, timesteps, shared_noise
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_util import CASES, CH_STRIDE_FULL, make_inputs, add_lora  # noqa: E402  (shared with the tests)
 
 
 def build_oracle(lora=False, seed=WEIGHT_SEED):
@@ -54,25 +36,8 @@ def build_oracle(lora=False, seed=WEIGHT_SEED):
     return vae.eval(), unet.eval()
 
 
-def add_lora(unet, LoraConfig, seed=WEIGHT_SEED):
-    """Two adapters as `--lora_configs default_r8_a8 Depth_r8_a16` would create (mtmadise.py:48-54,115-127);
-    'Depth' active.  A and B get seeded non-trivial values (B = 0 would make the adapter a no-op)."""
-    unet.add_adapter(LoraConfig(r=8, lora_alpha=8), "default")
-    unet.add_adapter(LoraConfig(r=8, lora_alpha=16), "Depth")
-    unet.set_adapter(["default", "Depth"])
-    with torch.no_grad():
-        for name, p in unet.named_parameters():
-            if ".lora_" in name:
-                g = weights._gen(seed, "unet." + name)
-                p.copy_(torch.randn(p.shape, generator=g) / (p.shape[1] ** 0.5))
-    for m in unet.modules():
-        if hasattr(m, "_active_adapter"):
-            m._active_adapter = ["Depth"]
-
-
 def run_reference(ref, vae, unet, sched, case):
-    images, cond_inputs, cond_emb, timesteps, shared_noise = make_inputs(case["B"], case["H"], case["W"], case["t"],
-                                                                         case["cond_scale"])
+    images, cond_inputs, cond_emb, timesteps, shared_noise = make_inputs(**case)
     with torch.no_grad():
         x = (images - 0.5) / 0.5   # LdmDiffusers.forward :145-146
         latents, _ = ref.vae_encoder(vae=vae, images=x, encoder_block_indices=[])
@@ -84,12 +49,15 @@ def run_reference(ref, vae, unet, sched, case):
 
 
 def main():
+    only = sys.argv[1:]
     assert ref_driver.available(), "needs /root/reference"
     ref = ref_driver.load()
     sched = sd_modules.DDPMScheduler()
     torch.set_num_threads(os.cpu_count())
     models = {}
     for name, case in CASES.items():
+        if only and name not in only:
+            continue
         key = case["lora"]
         if key not in models:
             models[key] = build_oracle(lora=key)

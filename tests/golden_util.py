@@ -42,8 +42,11 @@ def add_lora(unet, LoraConfig, seed=WEIGHT_SEED):
     with torch.no_grad():
         for name, p in unet.named_parameters():
             if ".lora_" in name:
+                # A ~ N(0, 1/K) keeps x A^T O(1); B ~ 0.1 N(0, 1/r): a ~10-20 % perturbation of the base
+                # layer (B = 0, peft's init, would make the adapter a no-op)
                 g = weights._gen(seed, "unet." + name)
-                p.copy_((torch.randn(p.shape, generator=g) / (p.shape[1] ** 0.5)).to(p.device))
+                gain = 0.1 if ".lora_B." in name else 1.0
+                p.copy_((gain * torch.randn(p.shape, generator=g) / (p.shape[1] ** 0.5)).to(p.device))
     for m in unet.modules():
         if hasattr(m, "_active_adapter"):
             m._active_adapter = ["Depth"]
