@@ -67,7 +67,7 @@ def kernel_profile(model, inputs):
     finally:
         ops.PROFILE = None
     agg = {}
-    for name, flops, e0, e1 in rec:
+    for name, flops, e0, e1, _ in rec:
         n, ms, fl = agg.get(name, (0, 0.0, 0.0))
         agg[name] = (n + 1, ms + e0.elapsed_time(e1), fl + flops)
     return agg

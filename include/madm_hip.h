@@ -70,9 +70,10 @@ const char* madm_last_error(void);
  * ------------------------------------------------------------------------------- */
 typedef struct {
     int dtype;            /* madm_dtype */
-    const void* in1;      /* [B, IH, IW, C1] */
+    const void* in1;      /* [B, IH, IW, C1] (pixel stride ld1); 16-byte aligned, < 2 GiB */
     const void* in2;      /* [B, IH, IW, C2] or NULL when C2 == 0 */
     int C1, C2;           /* multiples of the K-tile: 64 (bf16) / 32 (f32) elements */
+    int ld1, ld2;         /* pixel (row) strides of the sources in elements; 0 = dense (C1 / C2) */
     int B, IH, IW;        /* source dims (before the optional 2x upsample) */
     int OH, OW;
     int KH, KW;           /* 1x1 or 3x3 (any odd size works) */

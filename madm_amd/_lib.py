@@ -26,6 +26,7 @@ class Conv2dArgs(ctypes.Structure):
         ("dtype", c_int),
         ("in1", c_void_p), ("in2", c_void_p),
         ("C1", c_int), ("C2", c_int),
+        ("ld1", c_int), ("ld2", c_int),
         ("B", c_int), ("IH", c_int), ("IW", c_int),
         ("OH", c_int), ("OW", c_int),
         ("KH", c_int), ("KW", c_int),

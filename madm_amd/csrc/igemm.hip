@@ -12,11 +12,14 @@
 
 namespace {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 struct IgemmP {
     const char* in1; const char* in2; const char* w;
     const float* bias; const float* rowvec; const char* residual; char* out; float* ws;
     int C1, C2, Ctot, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
-    int N, K, M, ldr, ldo, ldrv, epilogue, splitk, tilesN, nk;
+    int N, K, M, ldr, ldo, ldrv, epilogue, splitk, tilesN, nk, ld1, ld2;
+    unsigned bytes1, bytes2, bytesw;
 };
 
 template <typename T>
@@ -64,6 +67,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     const int chunk = tid & 7, lrow = tid >> 3;
 
     // ---- per-thread gather state: RA pixels of the A tile, RB rows of the weight tile ----
+    // All global reads are raw buffer loads: an out-of-range voffset (padding pixels, rows beyond
+    // M / N) returns zeros, so the gather is branch-free.
+    constexpr unsigned OOB = 0x80000000u;
     int a_b[RA], a_iy[RA], a_ix[RA];
     const int OHW = p.OH * p.OW;
 #pragma unroll
@@ -74,17 +80,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             const int r = m - b * OHW;
             const int oy = r / p.OW;
             const int ox = r - oy * p.OW;
-            a_b[i] = b; a_iy[i] = oy * p.stride - p.pad_t; a_ix[i] = ox * p.stride - p.pad_l;
+            a_b[i] = b * p.IH; a_iy[i] = oy * p.stride - p.pad_t; a_ix[i] = ox * p.stride - p.pad_l;
         } else {
-            a_b[i] = -1; a_iy[i] = 0; a_ix[i] = 0;
+            a_b[i] = 0; a_iy[i] = -(1 << 24); a_ix[i] = 0;  // never in range
         }
     }
-    const char* wrow[RB];
+    unsigned wvoff[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int n = n0 + lrow + 32 * i;
-        wrow[i] = (n < p.N) ? p.w + ((size_t)n * p.K + chunk * EPC) * sizeof(T) : nullptr;
+        wvoff[i] = (n < p.N) ? (unsigned)(((size_t)n * p.K + chunk * EPC) * sizeof(T)) : OOB;
     }
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in2 ? p.in2 : p.in1), 0,
+                                                                         p.in2 ? p.bytes2 : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.bytesw, 0x00020000);
 
     const int kt0 = (int)(((long long)p.nk * z) / p.splitk);
     const int kt1 = (int)(((long long)p.nk * (z + 1)) / p.splitk);
@@ -99,43 +109,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     }
     const int IHe = p.upsample ? 2 * p.IH : p.IH;
     const int IWe = p.upsample ? 2 * p.IW : p.IW;
+    const int ush = p.upsample ? 1 : 0;
 
-    uint4 ra[RA], rb[RB];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    u32x4 ra[RA], rb[RB];
 
-#define IGEMM_LOAD_TILE(kt)                                                                     \
-    {                                                                                           \
-        const char* src; int Cs, cofs;                                                          \
-        if (c0 < p.C1) { src = p.in1; Cs = p.C1; cofs = c0; }                                   \
-        else           { src = p.in2; Cs = p.C2; cofs = c0 - p.C1; }                            \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                        \
-            uint4 v = zero4;                                                                    \
-            if (a_b[i] >= 0) {                                                                  \
-                int iy = a_iy[i] + tr, ix = a_ix[i] + ts;                                       \
-                if ((unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe) {             \
-                    if (p.upsample) { iy >>= 1; ix >>= 1; }                                     \
-                    const size_t off = ((size_t)(a_b[i] * p.IH + iy) * p.IW + ix) * Cs + cofs + \
-                                       chunk * EPC;                                             \
-                    v = *reinterpret_cast<const uint4*>(src + off * sizeof(T));                 \
-                }                                                                               \
-            }                                                                                   \
-            ra[i] = v;                                                                          \
-        }                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i) {                                        \
-            rb[i] = wrow[i] ? *reinterpret_cast<const uint4*>(wrow[i] + (size_t)(kt) * BKE * sizeof(T)) \
-                            : zero4;                                                            \
-        }                                                                                       \
-        c0 += BKE;                                                                              \
-        if (c0 >= p.Ctot) { c0 = 0; ++ts; if (ts == p.KW) { ts = 0; ++tr; } }                   \
+#define IGEMM_LOAD_TILE(kt)                                                                      \
+    {                                                                                            \
+        const bool first = c0 < p.C1;                                                            \
+        const __amdgpu_buffer_rsrc_t rs = first ? rs1 : rs2;                                     \
+        const int ld = first ? p.ld1 : p.ld2;                                                    \
+        const int cofs = (first ? c0 : c0 - p.C1) + chunk * EPC;                                 \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                         \
+            const int iy = a_iy[i] + tr, ix = a_ix[i] + ts;                                      \
+            const bool ok = (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;        \
+            const unsigned off = (unsigned)(((a_b[i] + (iy >> ush)) * p.IW + (ix >> ush)) * ld + cofs) * \
+                                 (unsigned)sizeof(T);                                            \
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);             \
+        }                                                                                        \
+        const unsigned kofs = (unsigned)(kt) * (unsigned)(BKE * sizeof(T));                      \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                           \
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], kofs, 0);               \
+        c0 += BKE;                                                                               \
+        if (c0 >= p.Ctot) { c0 = 0; ++ts; if (ts == p.KW) { ts = 0; ++tr; } }                    \
     }
 
-#define IGEMM_STORE_TILE(buf)                                                                   \
-    {                                                                                           \
-        uint4* sA = smem + (buf) * (BM + BN) * 8;                                               \
-        uint4* sB = sA + BM * 8;                                                                \
-        const int sw = chunk ^ (lrow & 7);                                                      \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i) sA[(lrow + 32 * i) * 8 + sw] = ra[i];    \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i) sB[(lrow + 32 * i) * 8 + sw] = rb[i];    \
+#define IGEMM_STORE_TILE(buf)                                                                    \
+    {                                                                                            \
+        u32x4* sA = reinterpret_cast<u32x4*>(smem) + (buf) * (BM + BN) * 8;                      \
+        u32x4* sB = sA + BM * 8;                                                                 \
+        const int sw = chunk ^ (lrow & 7);                                                       \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) sA[(lrow + 32 * i) * 8 + sw] = ra[i];     \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) sB[(lrow + 32 * i) * 8 + sw] = rb[i];     \
     }
 
     f32x4 acc[MI][NI];
@@ -154,7 +158,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
         const bool more = (kt + 1 < kt1);
+        // 1. issue the global loads of the next K-tile (they stay in flight during the MFMAs)
         if (more) IGEMM_LOAD_TILE(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // 2. MFMAs of the current tile
         {
             const uint4* sA = smem + cur * (BM + BN) * 8;
             const uint4* sB = sA + BM * 8;
@@ -172,6 +179,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
                     for (int j = 0; j < NI; ++j) mma16<T>(wf[j], af[i], acc[i][j]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // 3. only now wait for the loads and stage them into the other LDS buffer
         if (more) IGEMM_STORE_TILE(cur ^ 1);
         __syncthreads();
     }
@@ -260,6 +269,20 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     p.N = a->N; p.K = a->KH * a->KW * p.Ctot; p.M = a->B * a->OH * a->OW;
     MADM_REQUIRE(!a->rowvec || (a->ldrv >= a->N && a->ldrv % 4 == 0), "conv2d: bad ldrv=%d", a->ldrv);
     p.ldr = a->ldr; p.ldo = a->ldo; p.ldrv = a->ldrv; p.epilogue = a->epilogue;
+    p.ld1 = a->ld1 ? a->ld1 : a->C1;
+    p.ld2 = a->ld2 ? a->ld2 : a->C2;
+    MADM_REQUIRE(p.ld1 >= a->C1 && p.ld2 >= a->C2 && p.ld1 % (bke / 8) == 0 && p.ld2 % (bke / 8) == 0,
+                 "conv2d: bad source row strides ld1=%d ld2=%d", p.ld1, p.ld2);
+    {
+        const size_t es = (a->dtype == MADM_BF16) ? 2 : 4;
+        const size_t px = (size_t)a->B * a->IH * a->IW;
+        const size_t b1 = ((px - 1) * p.ld1 + a->C1) * es;
+        const size_t b2 = a->C2 ? ((px - 1) * p.ld2 + a->C2) * es : 0;
+        const size_t bw = (size_t)a->N * p.K * es;
+        MADM_REQUIRE(b1 < 0x80000000ull && b2 < 0x80000000ull && bw < 0x80000000ull,
+                     "conv2d: tensors must stay below 2 GiB (32-bit buffer offsets)");
+        p.bytes1 = (unsigned)b1; p.bytes2 = (unsigned)b2; p.bytesw = (unsigned)bw;
+    }
     p.nk = p.K / bke;
     p.splitk = a->splitk > p.nk ? p.nk : a->splitk;
     if (p.splitk < 1) p.splitk = 1;

@@ -49,8 +49,8 @@ _TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64"}
 
 
 class _Prof:
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops, desc=""):
+        self.name, self.flops, self.desc = name, flops, desc
 
     def __enter__(self):
         if PROFILE is not None:
@@ -62,7 +62,7 @@ class _Prof:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, self.e1))
+            PROFILE.append((self.name, self.flops, self.e0, self.e1, self.desc))
         return False
 
 
@@ -83,8 +83,8 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     _need_cuda(x1, w, x2, bias, rowvec, residual, out)
     C1 = x1.shape[1]
     C2 = 0 if x2 is None else x2.shape[1]
-    assert x1.is_contiguous() and x1.shape[0] == B * IH * IW, (x1.shape, B, IH, IW)
-    assert x2 is None or (x2.is_contiguous() and x2.shape[0] == x1.shape[0] and x2.dtype == x1.dtype)
+    assert x1.stride(1) == 1 and x1.shape[0] == B * IH * IW, (x1.shape, B, IH, IW)
+    assert x2 is None or (x2.stride(1) == 1 and x2.shape[0] == x1.shape[0] and x2.dtype == x1.dtype)
     assert w.dtype == x1.dtype and w.is_contiguous() and tuple(w.shape) == (N, KH * KW * (C1 + C2)), \
         (w.shape, N, KH, KW, C1, C2)
     if OH is None:
@@ -100,6 +100,8 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     a.in1 = x1.data_ptr()
     a.in2 = x2.data_ptr() if x2 is not None else None
     a.C1, a.C2 = C1, C2
+    a.ld1 = x1.stride(0)
+    a.ld2 = x2.stride(0) if x2 is not None else 0
     a.B, a.IH, a.IW, a.OH, a.OW = B, IH, IW, OH, OW
     a.KH, a.KW, a.stride, a.pad_t, a.pad_l = KH, KW, stride, pad_t, pad_l
     a.upsample = 1 if upsample else 0
@@ -134,7 +136,8 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     else:
         an, ak = alg_nk if alg_nk is not None else (N, KH * KW * (C1 + C2))
         name = _TILE_NAMES[lib.madm_conv2d_pick_tile(ctypes.byref(a))] + ("_f32" if x1.dtype == torch.float32 else "_bf16")
-        with _Prof(name, 2.0 * M * an * ak):
+        desc = f"M{M} N{N} K{KH * KW * (C1 + C2)} k{KH} s{stride}{' up' if upsample else ''} sk{a.splitk}"
+        with _Prof(name, 2.0 * M * an * ak, desc):
             check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     return out
 
@@ -215,7 +218,8 @@ def attention(q, k, v, B, H, Lq, Lk, D, scale, out=None):
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.B, a.H, a.Lq, a.Lk, a.D = B, H, Lq, Lk, D
     a.scale = float(scale)
-    with _Prof(f"attn_d{D}" + ("_f32" if q.dtype == torch.float32 else "_bf16"), 4.0 * B * H * Lq * Lk * D):
+    with _Prof(f"attn_d{D}" + ("_f32" if q.dtype == torch.float32 else "_bf16"), 4.0 * B * H * Lq * Lk * D,
+               f"B{B} H{H} Lq{Lq} Lk{Lk}"):
         check(lib.madm_attention_fwd(ctypes.byref(a), _stream()), "madm_attention_fwd")
     return out
 
