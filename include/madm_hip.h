@@ -90,6 +90,9 @@ typedef struct {
     void* out;            /* [M][ldo] of dtype, M = B*OH*OW */
     int ldo;
     int epilogue;         /* madm_epilogue */
+    float* stats;         /* NULL, or f32 [B][N][2], zeroed by the caller: receives the per-(image, channel)
+                           * sum and sum of squares of the stored output -- the statistics pass of the
+                           * GroupNorm that consumes this tensor, fused into the producer's epilogue */
     int splitk;           /* >=1; >1 needs workspace (f32 [splitk][M][N]) */
     void* workspace;
     size_t workspace_bytes;
@@ -106,23 +109,24 @@ int madm_conv2d_pick_tile(const madm_conv2d_args* a);
 void madm_debug_set_conv_tile(int tile);
 
 /* ---------------------------------------------------------------------------------
- * GroupNorm (32 groups in SD-v1-4; any G dividing Ctot), channels-last.  The normalised tensor
- * has Ctot channels and may be the channel concatenation of several sources (the skip concat
- * of the up blocks, ldm_diffusers.py:370,409): each call handles one dense source x
- * [B*HW][C] that occupies channels [c_off, c_off + C) of the concatenation.
- *   stats: adds the source's per-(b, group) sum and sum of squares into f64 `sums`[B][G][2]
- *          (caller zeroes `sums` first; one call per source).
- *   apply: y[.., c_off + c] = (x - mean) * rstd * gamma[c_off + c] + beta[c_off + c], optionally
- *          followed by SiLU; y has row stride ldy (>= Ctot for a concatenated output).
+ * GroupNorm (32 groups in SD-v1-4; any G dividing Ctot), channels-last.  The normalised tensor has
+ * Ctot channels and may be the channel concatenation [source 1 | source 2] (the skip concat of the up
+ * blocks, ldm_diffusers.py:370,409).  Statistics are per-(image, channel) f32 (sum, sum of squares)
+ * arrays `chsums` [B][C][2], one per source: produced either by the epilogue of the conv that wrote
+ * the source (madm_conv2d_args.stats) or by madm_groupnorm_stats.
+ *   stats: adds x's channel sums into the caller-zeroed chsums[B][C][2].
+ *   apply: y[.., c_off + c] = (x - mean_g) * rstd_g * gamma[c_off + c] + beta[c_off + c] (+ SiLU) for the
+ *          dense source x [B*HW][C] occupying channels [c_off, c_off + C) of the concatenation; group
+ *          statistics come from sums1 (channels [0, C1)) and sums2 (channels [C1, Ctot), may be NULL
+ *          when C1 == Ctot); y has row stride ldy.
  * Replaces diffusers ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm,
  * Attention.group_norm (VAE), conv_norm_out + conv_act
  * (ldm_diffusers.py:290,297,299-300,387,435,553,609-610).
  * ------------------------------------------------------------------------------- */
-int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int c_off, int Ctot,
-                         int G, double* sums, void* stream);
+int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, float* chsums, void* stream);
 int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int HW, int C,
-                         int c_off, int Ctot, int G, const double* sums, const float* gamma,
-                         const float* beta, float eps, int silu, void* stream);
+                         int c_off, int Ctot, int G, const float* sums1, int C1, const float* sums2,
+                         const float* gamma, const float* beta, float eps, int silu, void* stream);
 
 /* LayerNorm over the last dim of [M][C] (BasicTransformerBlock.norm1/2/3, eps 1e-5). */
 int madm_layernorm_fwd(int dtype, const void* x, void* y, int M, int C,
@@ -156,6 +160,13 @@ int madm_attention_fwd(const madm_attention_args* a, void* stream);
  * a mid-forward sync. */
 int madm_image_to_nhwc(int dtype, const float* img, void* out, int B, int C, int H, int W,
                        int Cpad, float mean, float std, float* minmax, void* stream);
+
+/* Same normalisation, but emitting the im2col rows of the VAE encoder's 3x3 / pad-1 stem conv
+ * (vae.encoder.conv_in, ldm_diffusers.py:287): out[pixel][k], k = (kh*3 + kw)*3 + c for the 27 taps,
+ * zero for k in [27, Kpad) and outside the image, so the 3->128 stem runs as a K = Kpad GEMM instead
+ * of a 3x3 conv over channel-padded pixels (9x fewer MFMAs on a layer that is 95 % padding). */
+int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H, int W, int Kpad,
+                            float mean, float std, float* minmax, void* stream);
 
 /* moments [B*HW][ldm] (dtype; channels 0..3 = posterior mean) ->
  *   latents_nchw[B,4,h,w] f32 = mean * scaling_factor                     (ldm_diffusers.py:303-308)

@@ -43,6 +43,7 @@ class Conv2dArgs(ctypes.Structure):
         ("out", c_void_p),
         ("ldo", c_int),
         ("epilogue", c_int),
+        ("stats", c_void_p),
         ("splitk", c_int),
         ("workspace", c_void_p),
         ("workspace_bytes", c_size_t),
@@ -68,15 +69,16 @@ SYMBOLS = [
     ("madm_conv2d_pick_tile", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_fwd", c_int, [ctypes.POINTER(Conv2dArgs), c_void_p]),
     ("madm_debug_set_conv_tile", None, [c_int]),
-    ("madm_groupnorm_stats", c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                     c_void_p]),
+    ("madm_groupnorm_stats", c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("madm_groupnorm_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
+                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     ("madm_layernorm_fwd", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
                                    c_void_p]),
     ("madm_attention_fwd", c_int, [ctypes.POINTER(AttentionArgs), c_void_p]),
     ("madm_image_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                    c_float, c_void_p, c_void_p]),
+    ("madm_image_to_im2col3x3", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
+                                        c_void_p, c_void_p]),
     ("madm_latents_add_noise", c_int, [c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     ("madm_timestep_embedding", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -16,14 +16,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmP {
     const char* in1; const char* in2; const char* w;
-    const float* bias; const float* rowvec; const char* residual; char* out; float* ws;
+    const float* bias; const float* rowvec; const char* residual; char* out; float* ws; float* stats;
     int C1, C2, Ctot, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
     int N, K, M, ldr, ldo, ldrv, epilogue, splitk, tilesN, nk, ld1, ld2;
     unsigned bytes1, bytes2, bytesw;
 };
 
+// applies bias / time row / GEGLU / residual, stores 4 (2 for GEGLU) outputs, returns the stored values
 template <typename T>
-__device__ __forceinline__ void epilogue_store(const IgemmP& p, int m, int n, f32x4 v) {
+__device__ __forceinline__ f32x4 epilogue_store(const IgemmP& p, int m, int n, f32x4 v) {
     if (p.bias) {
         float4 b = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -42,12 +43,25 @@ __device__ __forceinline__ void epilogue_store(const IgemmP& p, int m, int n, f3
             o0 += TT<T>::ld(r); o1 += TT<T>::ld(r + 1);
         }
         store2<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + col, o0, o1);
+        return f32x4{o0, o1, 0.f, 0.f};
     } else {
         if (p.residual) {
             f32x4 r = load4<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
             v += r;
         }
         store4<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+        return v;
+    }
+}
+
+// slow path of the fused GroupNorm statistics: one atomic pair per element (tiles that straddle images)
+__device__ __forceinline__ void stats_add_elementwise(const IgemmP& p, int m, int n, f32x4 v) {
+    const int bi = m / (p.OH * p.OW);
+    float* s = p.stats + ((size_t)bi * p.N + n) * 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        atomicAdd(s + 2 * r, v[r]);
+        atomicAdd(s + 2 * r + 1, v[r] * v[r]);
     }
 }
 
@@ -188,40 +202,103 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 #undef IGEMM_STORE_TILE
 
     // ---- epilogue: lane holds pixel m (lane & 15), channels n .. n+3 (4 * (lane >> 4)) ----
+    // Optional fused GroupNorm statistics of the OUTPUT tensor: per-(image, channel) sum and sum of
+    // squares (f32) accumulated in stats[B][N][2] -- the consumer GroupNorm then needs no pass of its own.
+    const bool want_stats = p.stats != nullptr && p.splitk == 1;
+    int mlast = m0 + BM; if (mlast > p.M) mlast = p.M; mlast -= 1;
+    const int img0 = m0 / OHW;
+    const bool one_image = (mlast / OHW) == img0;   // block-uniform
+    float* red = reinterpret_cast<float*>(smem);     // [2 (wm)][BN][2], reuses the staging LDS
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + frow;
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + fg * 4;
+        f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f}, cq = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + fg * 4;
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + frow;
             if (m < p.M && n < p.N) {
                 if (p.splitk > 1) {
                     f32x4 v = acc[i][j];
                     *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n) =
                         make_float4(v[0], v[1], v[2], v[3]);
                 } else {
-                    epilogue_store<T>(p, m, n, acc[i][j]);
+                    const f32x4 v = epilogue_store<T>(p, m, n, acc[i][j]);
+                    if (want_stats) {
+                        if (one_image) { cs += v; cq += v * v; }
+                        else stats_add_elementwise(p, m, n, v);
+                    }
                 }
             }
+        }
+        if (want_stats && one_image) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cs[r] += __shfl_xor(cs[r], o);
+                    cq[r] += __shfl_xor(cq[r], o);
+                }
+            }
+            if (frow == 0) {
+                float* dst = red + ((wm * BN) + wn * (BN / 2) + j * 16 + fg * 4) * 2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { dst[2 * r] = cs[r]; dst[2 * r + 1] = cq[r]; }
+            }
+        }
+    }
+    if (want_stats && one_image) {
+        __syncthreads();
+        for (int c = tid; c < 2 * BN; c += 256) {   // c = channel * 2 + {sum, sumsq}
+            const int n = n0 + (c >> 1);
+            if (n < p.N) atomicAdd(p.stats + ((size_t)img0 * p.N + n0) * 2 + c, red[c] + red[2 * BN + c]);
         }
     }
 }
 
-// sums the split-K slabs and applies the epilogue
+// sums the split-K slabs and applies the epilogue (+ the fused GroupNorm statistics).
+// Block = 16 channel quads x 16 row lanes, 4 rows per thread: a 64-row x 64-channel output tile.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
-    const size_t n4 = (size_t)p.N / 4;
-    const size_t total = (size_t)p.M * n4;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int m = (int)(idx / n4);
-        const int n = (int)(idx - (size_t)m * n4) * 4;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int zz = 0; zz < p.splitk; ++zz) {
-            float4 t = *reinterpret_cast<const float4*>(p.ws + ((size_t)zz * p.M + m) * p.N + n);
-            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    __shared__ float red[16][64][2];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int n = (blockIdx.x * 16 + tx) * 4;
+    const int mbase = blockIdx.y * 64;
+    const int OHW = p.OH * p.OW;
+    int mlast = mbase + 64; if (mlast > p.M) mlast = p.M; mlast -= 1;
+    const int img0 = mbase / OHW;
+    const bool one_image = (mlast / OHW) == img0;
+    const bool want_stats = p.stats != nullptr;
+    f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f}, cq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = mbase + ty + 16 * r;
+        if (m < p.M && n < p.N) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int zz = 0; zz < p.splitk; ++zz) {
+                float4 t = *reinterpret_cast<const float4*>(p.ws + ((size_t)zz * p.M + m) * p.N + n);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            v = epilogue_store<T>(p, m, n, v);
+            if (want_stats) {
+                if (one_image) { cs += v; cq += v * v; }
+                else stats_add_elementwise(p, m, n, v);
+            }
         }
-        epilogue_store<T>(p, m, n, v);
+    }
+    if (want_stats && one_image) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[ty][tx * 4 + r][0] = cs[r]; red[ty][tx * 4 + r][1] = cq[r]; }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int c = threadIdx.x >> 1, w = threadIdx.x & 1;
+            const int nn = blockIdx.x * 64 + c;
+            if (nn < p.N) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a += red[k][c][w];
+                atomicAdd(p.stats + ((size_t)img0 * p.N + nn) * 2 + w, a);
+            }
+        }
     }
 }
 
@@ -261,7 +338,8 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     MADM_REQUIRE(!a->residual || (a->ldr >= ocols && a->ldr % 2 == 0), "conv2d: bad ldr");
     p.in1 = (const char*)a->in1; p.in2 = (const char*)a->in2; p.w = (const char*)a->w;
     p.bias = a->bias; p.rowvec = a->rowvec; p.residual = (const char*)a->residual;
-    p.out = (char*)a->out; p.ws = (float*)a->workspace;
+    p.out = (char*)a->out; p.ws = (float*)a->workspace; p.stats = a->stats;
+    MADM_REQUIRE(!a->stats || a->epilogue == MADM_EPI_NONE, "conv2d: fused statistics need the plain epilogue");
     p.C1 = a->C1; p.C2 = a->C2; p.Ctot = a->C1 + a->C2;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW;
     p.KH = a->KH; p.KW = a->KW; p.stride = a->stride; p.pad_t = a->pad_t; p.pad_l = a->pad_l;
@@ -304,10 +382,8 @@ int launch(const IgemmP& p0, hipStream_t s) {
     int rc = madm_check_launch("igemm_kernel");
     if (rc) return rc;
     if (p.splitk > 1) {
-        const size_t total = (size_t)p.M * (p.N / 4);
-        unsigned blocks = (unsigned)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        splitk_reduce_kernel<T><<<blocks, 256, 0, s>>>(p);
+        dim3 rgrid((unsigned)((p.N / 4 + 15) / 16), (unsigned)((p.M + 63) / 64));
+        splitk_reduce_kernel<T><<<rgrid, 256, 0, s>>>(p);
         rc = madm_check_launch("splitk_reduce_kernel");
     }
     return rc;

@@ -46,6 +46,56 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
     }
 }
 
+// NCHW f32 3-channel image -> im2col rows of the 3x3/pad-1 stem conv: out[pixel][k], k = (r*3+s)*3 + c
+// holding (img[c, y+r-1, x+s-1] - mean) / std (zero outside the image: the conv pads the NORMALISED
+// image), k >= 27 zero.  One thread per (pixel, 16-byte chunk): coalesced 16-byte stores.
+template <typename T>
+__global__ __launch_bounds__(256) void image_to_im2col_kernel(const float* __restrict__ img, T* __restrict__ out,
+                                                              int B, int H, int W, int Kpad, float mean,
+                                                              float inv_std, float* minmax) {
+    constexpr int EPC = TT<T>::EPC;
+    const int CPR = Kpad / EPC;
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * HW * CPR;
+    float lo = INFINITY, hi = -INFINITY;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % CPR);
+        const size_t pix = idx / CPR;
+        const int b = (int)(pix / HW);
+        const int rem = (int)(pix - (size_t)b * HW);
+        const int y = rem / W, x = rem - y * W;
+        float f[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            const int k = q * EPC + j;
+            float v = 0.f;
+            if (k < 27) {
+                const int tap = k / 3, c = k - tap * 3;
+                const int r = tap / 3, s2 = tap - r * 3;
+                const int yy = y + r - 1, xx = x + s2 - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                    v = (img[((size_t)b * 3 + c) * HW + (size_t)yy * W + xx] - mean) * inv_std;
+                    if (tap == 4) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+                }
+            }
+            f[j] = v;
+        }
+        *reinterpret_cast<uint4*>(out + idx * EPC) = f32_to_chunk<T>(f);
+    }
+    if (minmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o));
+            hi = fmaxf(hi, __shfl_xor(hi, o));
+        }
+        if ((threadIdx.x & 63) == 0 && lo <= hi) {
+            atomicMin(&minmax[0], lo);
+            atomicMax(&minmax[1], hi);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void latents_add_noise_kernel(const T* __restrict__ moments, int ldm,
                                                                 float scaling, const float* __restrict__ noise,
@@ -158,6 +208,19 @@ int madm_image_to_nhwc(int dtype, const float* img, void* out, int B, int C, int
     MADM_DISPATCH_DTYPE(dtype, (image_to_nhwc_kernel<T><<<grid_for(total), 256, 0, s>>>(
                                    img, (T*)out, B, C, H * W, Cpad, mean, 1.0f / std, minmax)));
     return madm_check_launch("image_to_nhwc_kernel");
+}
+
+int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H, int W, int Kpad, float mean,
+                            float std, float* minmax, void* stream) {
+    MADM_REQUIRE(img && out, "image_to_im2col3x3: null pointer");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(B > 0 && H > 0 && W > 0 && Kpad >= 27 && Kpad % epc == 0, "image_to_im2col3x3: bad dims");
+    MADM_REQUIRE(std != 0.f, "image_to_im2col3x3: std == 0");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)B * H * W * (Kpad / epc);
+    MADM_DISPATCH_DTYPE(dtype, (image_to_im2col_kernel<T><<<grid_for(total, 8192), 256, 0, s>>>(
+                                   img, (T*)out, B, H, W, Kpad, mean, 1.0f / std, minmax)));
+    return madm_check_launch("image_to_im2col_kernel");
 }
 
 int madm_nchw_f32_to_nhwc(int dtype, const float* x, void* out, int B, int C, int HW, int Cpad, void* stream) {

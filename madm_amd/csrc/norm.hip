@@ -4,18 +4,16 @@
 
 namespace {
 
-// ---- GroupNorm statistics -------------------------------------------------------------
+// ---- GroupNorm statistics (stand-alone; the conv epilogue normally produces them) ----------
 // grid (splits, B).  A block owns rows [r0, r1) of image b.  Threads are laid out as
 // (column chunk, row lane); every thread keeps per-channel partial sums of its fixed 16-byte
-// column over its rows, adds them into per-channel LDS sums, and the block then folds channels
-// into groups and adds the result to the f64 global sums[b][g][2] (sum, sum of squares).
+// column over its rows, adds them into per-channel LDS sums, and the block adds those to the global
+// f32 chsums[b][c][2] (sum, sum of squares) with contiguous atomics.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int HW, int C, int c_off,
-                                                       int Ctot, int G, int rows_per_block, double* sums) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int HW, int C,
+                                                       int rows_per_block, float* chsums) {
     constexpr int EPC = TT<T>::EPC;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // [2][C]
-    float* csum = lds;
-    float* csq = lds + C;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // [C][2]
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_block;
     int r1 = r0 + rows_per_block;
@@ -42,54 +40,58 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
             }
 #pragma unroll
             for (int j = 0; j < EPC; ++j) {
-                atomicAdd(&csum[q * EPC + j], s[j]);
-                atomicAdd(&csq[q * EPC + j], ss[j]);
+                atomicAdd(&lds[(q * EPC + j) * 2], s[j]);
+                atomicAdd(&lds[(q * EPC + j) * 2 + 1], ss[j]);
             }
         }
     }
     __syncthreads();
-    // fold this source's channels [c_off, c_off + C) of the Ctot-channel tensor into its groups
-    const int cpg = Ctot / G;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        int lo = g * cpg - c_off, hi = (g + 1) * cpg - c_off;
-        if (lo < 0) lo = 0;
-        if (hi > C) hi = C;
-        if (lo >= hi) continue;
-        double a = 0.0, q = 0.0;
-        for (int c = lo; c < hi; ++c) { a += (double)csum[c]; q += (double)csq[c]; }
-        atomicAdd(&sums[((size_t)b * G + g) * 2 + 0], a);
-        atomicAdd(&sums[((size_t)b * G + g) * 2 + 1], q);
-    }
+    float* dst = chsums + (size_t)b * C * 2;
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(dst + c, lds[c]);
 }
 
 // ---- GroupNorm apply (+ optional SiLU) ---------------------------------------------------
-// grid (strips, B).  Per-channel scale/shift of image b are built once per block in LDS.
+// grid (strips, B).  Each block first folds the per-channel sums of the (possibly two-source)
+// Ctot-channel tensor into group mean / rstd (f64 arithmetic on the f32 sums), then builds the
+// per-channel scale/shift of its source in LDS and streams its rows.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int ldy,
                                                        int HW, int C, int c_off, int Ctot, int G,
-                                                       const double* __restrict__ sums,
+                                                       const float* __restrict__ sums1, int C1,
+                                                       const float* __restrict__ sums2,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu) {
     constexpr int EPC = TT<T>::EPC;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // scale[C], shift[C]
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // scale[C], shift[C], gmean[G], grstd[G]
     float* scale = lds;
     float* shift = lds + C;
+    float* gmean = lds + 2 * C;
+    float* grstd = gmean + G;
     const int b = blockIdx.y;
     const int cpg = Ctot / G;
     const double cnt = (double)HW * (double)cpg;
+    const int C2 = Ctot - C1;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) {
+            const float* src = (ch < C1) ? sums1 + ((size_t)b * C1 + ch) * 2 : sums2 + ((size_t)b * C2 + (ch - C1)) * 2;
+            s += (double)src[0];
+            q += (double)src[1];
+        }
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        gmean[g] = (float)mean;
+        grstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
     gamma += c_off;
     beta += c_off;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int g = (c_off + c) / cpg;
-        const double s = sums[((size_t)b * G + g) * 2 + 0];
-        const double q = sums[((size_t)b * G + g) * 2 + 1];
-        const double mean = s / cnt;
-        double var = q / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = rstd * gamma[c];
+        const float sc = grstd[g] * gamma[c];
         scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
+        shift[c] = beta[c] - gmean[g] * sc;
     }
     __syncthreads();
     const int CPR = C / EPC;
@@ -170,17 +172,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 
 extern "C" {
 
-int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int c_off, int Ctot, int G, double* sums,
-                         void* stream) {
-    MADM_REQUIRE(x && sums, "groupnorm_stats: null pointer");
-    MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && Ctot % G == 0 && c_off >= 0 && c_off + C <= Ctot,
-                 "groupnorm_stats: bad dims B=%d HW=%d C=%d c_off=%d Ctot=%d G=%d", B, HW, C, c_off, Ctot, G);
+int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, float* chsums, void* stream) {
+    MADM_REQUIRE(x && chsums, "groupnorm_stats: null pointer");
+    MADM_REQUIRE(B > 0 && HW > 0 && C > 0, "groupnorm_stats: bad dims B=%d HW=%d C=%d", B, HW, C);
     const int epc = dtype == MADM_BF16 ? 8 : 4;
-    MADM_REQUIRE(C % epc == 0 && c_off % epc == 0, "groupnorm_stats: C=%d / c_off=%d must be multiples of %d", C, c_off, epc);
+    MADM_REQUIRE(C % epc == 0, "groupnorm_stats: C=%d must be a multiple of %d", C, epc);
     MADM_REQUIRE((size_t)2 * C * sizeof(float) <= 64 * 1024, "groupnorm_stats: C=%d too large", C);
-    // enough blocks to fill the chip, at least 32 rows each
-    int splits = (HW + 31) / 32;
-    const int maxsplits = (2048 + B - 1) / B;
+    // enough blocks to fill the chip, at least 64 rows each
+    int splits = (HW + 63) / 64;
+    const int maxsplits = (1024 + B - 1) / B;
     if (splits > maxsplits) splits = maxsplits;
     if (splits < 1) splits = 1;
     const int rows_per_block = (HW + splits - 1) / splits;
@@ -188,29 +188,30 @@ int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, int c_o
     dim3 grid((unsigned)splits, (unsigned)B);
     const size_t shm = (size_t)2 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    MADM_DISPATCH_DTYPE(dtype, (gn_stats_kernel<T><<<grid, 256, shm, s>>>((const T*)x, HW, C, c_off, Ctot, G, rows_per_block, sums)));
+    MADM_DISPATCH_DTYPE(dtype, (gn_stats_kernel<T><<<grid, 256, shm, s>>>((const T*)x, HW, C, rows_per_block, chsums)));
     return madm_check_launch("gn_stats_kernel");
 }
 
 int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int HW, int C, int c_off, int Ctot,
-                         int G, const double* sums, const float* gamma, const float* beta, float eps, int silu,
-                         void* stream) {
-    MADM_REQUIRE(x && y && sums && gamma && beta, "groupnorm_apply: null pointer");
+                         int G, const float* sums1, int C1, const float* sums2, const float* gamma,
+                         const float* beta, float eps, int silu, void* stream) {
+    MADM_REQUIRE(x && y && sums1 && gamma && beta, "groupnorm_apply: null pointer");
     MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && Ctot % G == 0 && c_off >= 0 && c_off + C <= Ctot && ldy >= c_off + C,
                  "groupnorm_apply: bad dims");
+    MADM_REQUIRE(C1 > 0 && C1 <= Ctot && (C1 == Ctot || sums2), "groupnorm_apply: bad statistics sources (C1=%d Ctot=%d)", C1, Ctot);
     const int epc = dtype == MADM_BF16 ? 8 : 4;
     MADM_REQUIRE(C % epc == 0 && c_off % epc == 0 && ldy % epc == 0, "groupnorm_apply: C/c_off/ldy must be multiples of %d", epc);
-    MADM_REQUIRE((size_t)2 * C * sizeof(float) <= 64 * 1024, "groupnorm_apply: C=%d too large", C);
+    const size_t shm = ((size_t)2 * C + 2 * G) * sizeof(float);
+    MADM_REQUIRE(shm <= 64 * 1024, "groupnorm_apply: C=%d too large", C);
     const size_t total = (size_t)HW * (C / epc);
-    size_t strips = (total + 256 * 4 - 1) / (256 * 4);
-    const size_t maxstrips = (size_t)(4096 + B - 1) / B;
+    size_t strips = (total + 256 * 8 - 1) / (256 * 8);
+    const size_t maxstrips = (size_t)(2048 + B - 1) / B;
     if (strips > maxstrips) strips = maxstrips;
     if (strips < 1) strips = 1;
     dim3 grid((unsigned)strips, (unsigned)B);
-    const size_t shm = (size_t)2 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    MADM_DISPATCH_DTYPE(dtype, (gn_apply_kernel<T><<<grid, 256, shm, s>>>((const T*)x, (T*)y, ldy, HW, C, c_off, Ctot, G, sums,
-                                                                        gamma, beta, eps, silu)));
+    MADM_DISPATCH_DTYPE(dtype, (gn_apply_kernel<T><<<grid, 256, shm, s>>>((const T*)x, (T*)y, ldy, HW, C, c_off, Ctot, G,
+                                                                        sums1, C1, sums2, gamma, beta, eps, silu)));
     return madm_check_launch("gn_apply_kernel");
 }
 

@@ -41,7 +41,9 @@ def _compute_dtype(m):
 
 
 def _img_tokens(images, dtype, mean=0.0, std=1.0, minmax=None):
-    return Tok(ops.image_to_nhwc(images.float().contiguous(), dtype, ops.k_tile(dtype), mean, std, minmax),
+    """Normalised image as the im2col rows of the VAE stem conv (sd_vae.AutoencoderKL.encode_moments)."""
+    assert images.shape[1] == 3, "the SD VAE encoder takes 3-channel images"
+    return Tok(ops.image_to_im2col3x3(images.float().contiguous(), dtype, ops.k_tile(dtype), mean, std, minmax),
                images.shape[0], images.shape[2], images.shape[3])
 
 
@@ -50,6 +52,7 @@ def vae_encoder(vae, images, encoder_block_indices):
     """Reference signature (ldm_diffusers.py:283-311): images [B,3,H,W] in [-1,1] (NCHW) ->
     (latents [B,4,H/8,W/8] f32 = posterior.mean * scaling_factor, list of tap tensors NCHW)."""
     dtype = _compute_dtype(vae)
+    ops.ARENA.reset(images.device)
     x = _img_tokens(images, dtype)
     moments, taps = vae.encode_moments(x, tuple(encoder_block_indices))
     B, h, w = moments.B, moments.H, moments.W
@@ -121,6 +124,7 @@ def diffusion_unet(unet, sample, timestep, encoder_hidden_states, res_time_embed
     ``encoder_hidden_states`` [B,77,768], ``res_time_embedding`` [B,1,1280]|[B,1280]|None ->
     (namespace(sample=[B,4,h,w]), list of tap tensors NCHW f32)."""
     dtype = _compute_dtype(unet)
+    ops.ARENA.reset(sample.device)
     B, C, h, w = sample.shape
     x = Tok(ops.nchw_to_nhwc(sample.float().contiguous(), dtype, ops.k_tile(dtype)), B, h, w)
     out, taps = _unet_tokens(unet, x, timestep, encoder_hidden_states, res_time_embedding, unet_block_indices,
@@ -284,6 +288,7 @@ class LdmRocm(nn.Module):
         dtype = self.compute_dtype
         dev = images.device
         B, _, H, W = images.shape
+        ops.ARENA.reset(dev)
         mean, std = (self.input_mean, self.input_std) if self.input_range == '-1+1' else (0.0, 1.0)
         minmax = None
         if self.input_range == '-1+1':   # device-to-device reset: capture-safe (no host memcpy in the graph)

@@ -14,11 +14,14 @@ from . import ops, packing
 
 class Tok:
     """Channels-last activation: ``t`` is [B*H*W, C] (contiguous), plus its image geometry."""
-    __slots__ = ("t", "B", "H", "W")
+    __slots__ = ("t", "B", "H", "W", "stats")
 
-    def __init__(self, t, B, H, W):
+    def __init__(self, t, B, H, W, stats=None):
         assert t.dim() == 2 and t.shape[0] == B * H * W, (t.shape, B, H, W)
         self.t, self.B, self.H, self.W = t, B, H, W
+        # f32 [B, C, 2] per-(image, channel) sum / sum of squares written by the producing kernel's
+        # epilogue (None: a consuming GroupNorm computes them itself)
+        self.stats = stats
 
     @property
     def C(self):
@@ -112,8 +115,9 @@ class Conv2d(_Packed):
         p = self.padding
         return (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
 
-    def forward(self, x, x2=None, upsample=False, rowvec=None, residual=None, out=None):
-        """x (and optional x2 = channel-concatenated second source) are Tok; returns Tok."""
+    def forward(self, x, x2=None, upsample=False, rowvec=None, residual=None, out=None, stats=True):
+        """x (and optional x2 = channel-concatenated second source) are Tok; returns Tok.  ``stats``:
+        also emit the GroupNorm statistics of the output from the epilogue (Tok.stats)."""
         dtype = x.t.dtype
         splits = None
         if x2 is not None:
@@ -122,12 +126,13 @@ class Conv2d(_Packed):
         wp, b = self.packed(dtype, splits)
         OH, OW = self.out_hw(x.H, x.W, upsample)
         pad = 0 if self.asym_pad else self.padding
+        st = ops.new_chsums(x.B, self.n_pad, x.t.device) if stats else None
         o = ops.conv2d(x.t, wp, x.B, x.H, x.W, N=self.n_pad, x2=None if x2 is None else x2.t,
                        KH=self.kernel_size, KW=self.kernel_size, stride=self.stride, pad_t=pad, pad_l=pad,
                        OH=OH, OW=OW, upsample=upsample, bias=b, rowvec=rowvec,
                        residual=None if residual is None else residual.t, out=out,
-                       alg_nk=(self.out_channels, self.kernel_size * self.kernel_size * self.in_channels))
-        return Tok(o, x.B, OH, OW)
+                       alg_nk=(self.out_channels, self.kernel_size * self.kernel_size * self.in_channels), stats=st)
+        return Tok(o, x.B, OH, OW, st)
 
 
 class Linear(_Packed):
@@ -145,10 +150,10 @@ class Linear(_Packed):
 
         return self._cache_get((dtype, "lin"), build)
 
-    def forward(self, x, residual=None, out=None):
+    def forward(self, x, residual=None, out=None, stats=None, B=1):
         """x: [M, K] dense 2-D tensor of the compute dtype."""
         wp, b = self.packed(x.dtype)
-        return ops.linear(x, wp, bias=b, residual=residual, out=out)
+        return ops.linear(x, wp, bias=b, residual=residual, out=out, stats=stats, B=B)
 
 
 class GroupNorm(nn.Module):
@@ -161,8 +166,9 @@ class GroupNorm(nn.Module):
     def forward(self, x, silu=False, x2=None):
         """GroupNorm(+SiLU) of x, or of the channel concatenation [x | x2]; returns one dense Tok."""
         xs = [x.t] if x2 is None else [x.t, x2.t]
+        st = [x.stats] if x2 is None else [x.stats, x2.stats]
         t = ops.groupnorm(xs, x.B, x.HW, self.num_groups, self.weight.detach(), self.bias.detach(), self.eps,
-                          silu=silu)
+                          silu=silu, stats=st)
         return x.like(t)
 
 

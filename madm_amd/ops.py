@@ -77,7 +77,7 @@ def _workspace(nbytes, device):
 
 def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
            upsample=False, bias=None, rowvec=None, residual=None, epilogue=EPI_NONE, out=None,
-           splitk=None, alg_nk=None):
+           splitk=None, alg_nk=None, stats=None):
     """Implicit-GEMM conv / linear.  x1: [B*IH*IW, C1] dense; x2 optional second source (concat);
     w: packed [N, KH*KW*(C1+C2)]; returns out [B*OH*OW, N] (N/2 columns for GEGLU)."""
     _need_cuda(x1, w, x2, bias, rowvec, residual, out)
@@ -121,6 +121,9 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     a.out = out.data_ptr()
     a.ldo = out.stride(0)
     a.epilogue = epilogue
+    if stats is not None:
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() == B * N * 2
+        a.stats = stats.data_ptr()
     a.splitk = 1
     if splitk is None:
         splitk = lib.madm_conv2d_suggest_splitk(ctypes.byref(a))
@@ -142,53 +145,85 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     return out
 
 
-def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=None, splitk=None, alg_nk=None):
-    """out = x @ w.T (+bias) (+residual); x: [M, K] dense, w: [N, K(+K2)]."""
-    return conv2d(x, w, 1, x.shape[0], 1, N=w.shape[0], x2=x2, bias=bias, residual=residual,
-                  epilogue=epilogue, out=out, splitk=splitk, alg_nk=alg_nk)
+def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=None, splitk=None, alg_nk=None,
+           stats=None, B=1):
+    """out = x @ w.T (+bias) (+residual); x: [M, K] dense, w: [N, K(+K2)].  ``stats`` ([B, N, 2]) asks for
+    the fused GroupNorm statistics of the output, the M rows being B images of M/B tokens."""
+    M = x.shape[0]
+    assert M % B == 0
+    return conv2d(x, w, B, M // B, 1, N=w.shape[0], x2=x2, bias=bias, residual=residual,
+                  epilogue=epilogue, out=out, splitk=splitk, alg_nk=alg_nk, stats=stats)
 
 
-def groupnorm_stats(x, B, HW, G, sums, c_off=0, Ctot=None):
-    """Adds (sum, sum of squares) per (b, group) of source ``x`` -- channels [c_off, c_off+C) of a
-    Ctot-channel tensor -- into the f64 tensor ``sums`` [B, G, 2], which the caller has zeroed."""
-    _need_cuda(x, sums)
+class StatsArena:
+    """Zero-initialised f32 scratch for the fused GroupNorm statistics: ONE memset per forward instead
+    of one per layer.  ``reset()`` at the start of a forward allocates (and zeroes) the size the previous
+    forward needed; ``take(n)`` hands out slices and falls back to individual allocations on overflow."""
+
+    def __init__(self):
+        self.need = 0
+        self.buf = None
+        self.off = 0
+        self.used = 0
+
+    def reset(self, device):
+        self.need = max(self.need, self.used)
+        self.buf = torch.zeros(self.need, dtype=torch.float32, device=device) if self.need else None
+        self.off = 0
+        self.used = 0
+
+    def take(self, n, device):
+        n16 = (n + 15) // 16 * 16
+        self.used += n16
+        if self.buf is not None and self.buf.device == device and self.off + n16 <= self.buf.numel():
+            out = self.buf[self.off:self.off + n]
+            self.off += n16
+            return out
+        return torch.zeros(n, dtype=torch.float32, device=device)
+
+
+ARENA = StatsArena()
+
+
+def new_chsums(B, C, device):
+    """Zeroed per-(image, channel) statistics buffer [B, C, 2] (f32)."""
+    return ARENA.take(B * C * 2, device).view(B, C, 2)
+
+
+def groupnorm_stats(x, B, HW, chsums):
+    """Adds x's per-(image, channel) sum / sum of squares into the zeroed f32 ``chsums`` [B, C, 2]."""
+    _need_cuda(x, chsums)
     assert x.is_contiguous() and x.shape[0] == B * HW
-    assert sums.dtype == torch.float64 and sums.is_contiguous() and sums.numel() == B * G * 2
-    C = x.shape[1]
-    check(lib.madm_groupnorm_stats(dtype_code(x), x.data_ptr(), B, HW, C, c_off, C if Ctot is None else Ctot, G,
-                                   sums.data_ptr(), _stream()), "madm_groupnorm_stats")
+    assert chsums.dtype == torch.float32 and chsums.is_contiguous() and chsums.numel() == B * x.shape[1] * 2
+    check(lib.madm_groupnorm_stats(dtype_code(x), x.data_ptr(), B, HW, x.shape[1], chsums.data_ptr(), _stream()),
+          "madm_groupnorm_stats")
 
 
-def groupnorm_apply(x, B, HW, G, sums, gamma, beta, eps, silu, out=None, c_off=0, Ctot=None):
-    _need_cuda(x, sums, gamma, beta)
-    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
-    C = x.shape[1]
-    Ctot = C if Ctot is None else Ctot
-    if out is None:
-        out = torch.empty((x.shape[0], Ctot), dtype=x.dtype, device=x.device)
-    assert out.stride(1) == 1 and out.shape[1] >= Ctot and gamma.numel() == Ctot
-    check(lib.madm_groupnorm_apply(dtype_code(x), x.data_ptr(), out.data_ptr(), out.stride(0), B, HW, C, c_off,
-                                   Ctot, G, sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps),
-                                   1 if silu else 0, _stream()), "madm_groupnorm_apply")
-    return out
-
-
-def groupnorm(xs, B, HW, G, gamma, beta, eps, silu=False, sums=None):
-    """GroupNorm(+SiLU) of the channel concatenation of the sources ``xs`` (a tensor or a list of
-    [B*HW, C_i] tensors); returns the normalised [B*HW, sum C_i] tensor."""
+def groupnorm(xs, B, HW, G, gamma, beta, eps, silu=False, stats=None):
+    """GroupNorm(+SiLU) of the channel concatenation of one or two sources ``xs`` (a tensor or a list
+    of [B*HW, C_i] tensors); ``stats`` = matching list of chsums tensors [B, C_i, 2] (from the producing
+    conv's epilogue) or None entries (computed here).  Returns the normalised [B*HW, sum C_i] tensor."""
     if isinstance(xs, torch.Tensor):
         xs = [xs]
+    assert 1 <= len(xs) <= 2
+    stats = list(stats) if stats is not None else [None] * len(xs)
+    for i, x in enumerate(xs):
+        if stats[i] is None:
+            stats[i] = new_chsums(B, x.shape[1], x.device)
+            groupnorm_stats(x, B, HW, stats[i])
+    _need_cuda(gamma, beta, *xs)
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32
     Ctot = sum(x.shape[1] for x in xs)
-    if sums is None:
-        sums = torch.zeros((B, G, 2), dtype=torch.float64, device=xs[0].device)
-    off = 0
-    for x in xs:
-        groupnorm_stats(x, B, HW, G, sums, off, Ctot)
-        off += x.shape[1]
+    assert gamma.numel() == Ctot
     out = torch.empty((xs[0].shape[0], Ctot), dtype=xs[0].dtype, device=xs[0].device)
+    C1 = xs[0].shape[1]
+    s2 = stats[1].data_ptr() if len(xs) > 1 else None
     off = 0
     for x in xs:
-        groupnorm_apply(x, B, HW, G, sums, gamma, beta, eps, silu, out=out, c_off=off, Ctot=Ctot)
+        assert x.is_contiguous()
+        check(lib.madm_groupnorm_apply(dtype_code(x), x.data_ptr(), out.data_ptr(), out.stride(0), B, HW, x.shape[1],
+                                       off, Ctot, G, stats[0].data_ptr(), C1, s2, gamma.data_ptr(), beta.data_ptr(),
+                                       float(eps), 1 if silu else 0, _stream()), "madm_groupnorm_apply")
         off += x.shape[1]
     return out
 
@@ -231,6 +266,17 @@ def image_to_nhwc(img, dtype, Cpad, mean, std, minmax=None):
     out = torch.empty((B * H * W, Cpad), dtype=dtype, device=img.device)
     check(lib.madm_image_to_nhwc(dtype_code(dtype), img.data_ptr(), out.data_ptr(), B, C, H, W, Cpad,
                                  float(mean), float(std), _ptr(minmax), _stream()), "madm_image_to_nhwc")
+    return out
+
+
+def image_to_im2col3x3(img, dtype, Kpad, mean, std, minmax=None):
+    """[B,3,H,W] f32 -> im2col rows [B*H*W, Kpad] of the normalised image for a 3x3/pad-1 stem conv."""
+    _need_cuda(img, minmax)
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4 and img.shape[1] == 3
+    B, C, H, W = img.shape
+    out = torch.empty((B * H * W, Kpad), dtype=dtype, device=img.device)
+    check(lib.madm_image_to_im2col3x3(dtype_code(dtype), img.data_ptr(), out.data_ptr(), B, H, W, Kpad,
+                                      float(mean), float(std), _ptr(minmax), _stream()), "madm_image_to_im2col3x3")
     return out
 
 

@@ -211,7 +211,7 @@ class Transformer2DModel(nn.Module):
         self.proj_out = Conv2d(inner, in_channels, 1)
 
     def forward(self, x, ctx, Lk):
-        h = self.proj_in(self.norm(x))
+        h = self.proj_in(self.norm(x), stats=False)
         t = h.t
         for blk in self.transformer_blocks:
             t = blk(t, x.B, x.HW, ctx, Lk)
@@ -237,13 +237,13 @@ class ResnetBlock2D(nn.Module):
         if skip is None:
             h = self.norm1(x, silu=True)
             h = self.conv1(h, rowvec=temb_row)
-            res = x if self.conv_shortcut is None else self.conv_shortcut(x)
+            res = x if self.conv_shortcut is None else self.conv_shortcut(x, stats=False)
         else:
             # GroupNorm over the concatenated channels: the concat exists only as the normalised
             # copy written by the two-source GN; the 1x1 shortcut reads the two sources directly.
             h = self.norm1(x, silu=True, x2=skip)
             h = self.conv1(h, rowvec=temb_row)
-            res = self.conv_shortcut(x, x2=skip)
+            res = self.conv_shortcut(x, x2=skip, stats=False)
         h = self.norm2(h, silu=True)
         return self.conv2(h, residual=res)
 
@@ -491,4 +491,4 @@ class UNet2DConditionModel(nn.Module):
                     h = u(h)
         assert len(taps) == len(unet_block_indices)
         h = self.conv_norm_out(h, silu=True)
-        return self.conv_out(h), taps
+        return self.conv_out(h, stats=False), taps

@@ -34,7 +34,9 @@ class VaeAttention(nn.Module):
         h = self.group_norm(x)
         qkv = f_qkv(h.t)
         o = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, 1, x.HW, x.HW, C, C ** -0.5)
-        return x.like(self.to_out[0](o, residual=x.t))
+        st = ops.new_chsums(x.B, C, x.t.device)
+        out = self.to_out[0](o, residual=x.t, stats=st, B=x.B)
+        return Tok(out, x.B, x.H, x.W, st)
 
 
 class UNetMidBlock2D(nn.Module):
@@ -118,19 +120,30 @@ class AutoencoderKL(_Packed):
         self.post_quant_conv = Conv2d(latent_channels, latent_channels, 1)
 
     def _versions(self):
-        ps = [self.encoder.conv_out.weight, self.encoder.conv_out.bias, self.quant_conv.weight, self.quant_conv.bias,
+        ps = [self.encoder.conv_in.weight, self.encoder.conv_in.bias,
+              self.encoder.conv_out.weight, self.encoder.conv_out.bias, self.quant_conv.weight, self.quant_conv.bias,
               self.decoder.conv_in.weight, self.decoder.conv_in.bias, self.post_quant_conv.weight,
               self.post_quant_conv.bias]
         return tuple((p._version, p.data_ptr()) for p in ps)
 
     # ---- encoder: vae_encoder (ldm_diffusers.py:283-311) up to ``moments`` ----
     def encode_moments(self, x, encoder_block_indices=()):
-        """x: Tok of the normalised image (channels padded to the K-tile).  Returns
+        """x: Tok of the normalised image as im2col rows of the 3x3 stem (ops.image_to_im2col3x3).  Returns
         (moments Tok [.., 8] = quant_conv(encoder(x)), taps list[Tok]).  quant_conv (1x1, 8->8) is
         folded into encoder.conv_out's weights: W' = Wq W, b' = Wq b + bq (exact composition)."""
         enc = self.encoder
         taps, index = [], 0
-        h = enc.conv_in(x)
+        dtype = x.t.dtype
+
+        def build_stem():   # [128,3,3,3] -> [128][k = (r*3+s)*3 + c] padded to the K-tile
+            w = enc.conv_in.weight.detach().float().permute(0, 2, 3, 1).reshape(enc.conv_in.out_channels, 27)
+            return (packing.pack_linear_weight(w, dtype, ops.k_tile(dtype)),
+                    enc.conv_in.bias.detach().float().contiguous())
+
+        ws, bs = self._cache_get((dtype, "stem"), build_stem)
+        st = ops.new_chsums(x.B, ws.shape[0], x.t.device)
+        h = Tok(ops.linear(x.t, ws, bias=bs, alg_nk=(enc.conv_in.out_channels, 27), stats=st, B=x.B),
+                x.B, x.H, x.W, st)
         for blk in enc.down_blocks:
             for resnet in blk.resnets:
                 h = resnet(h)
@@ -142,7 +155,6 @@ class AutoencoderKL(_Packed):
                     h = d(h)
         h = enc.mid_block(h)
         h = enc.conv_norm_out(h, silu=True)
-        dtype = h.t.dtype
 
         def build():
             W = enc.conv_out.weight.detach().double()            # [8, 512, 3, 3]

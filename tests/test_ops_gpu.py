@@ -122,6 +122,58 @@ def test_groupnorm(cuda, dtype, shape, silu):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 1280, 640, 4, 4), (2, 320, 320, 8, 8), (1, 64, 128, 5, 3)])
+def test_groupnorm_two_sources(cuda, dtype, shape):
+    """GroupNorm over the skip concatenation [x | skip] without materialising the concat input; groups
+    may straddle the source boundary (1280 + 640 channels: 60 per group)."""
+    from madm_amd import ops
+    B, C1, C2, H, W = shape
+    x1 = _q(_gen((B, C1, H, W), 1) * 1.5 + 0.3, dtype)
+    x2 = _q(_gen((B, C2, H, W), 2) * 0.7 - 0.2, dtype)
+    gamma = _gen((C1 + C2,), 3)
+    beta = _gen((C1 + C2,), 4)
+    ref = F.silu(F.group_norm(torch.cat([x1, x2], 1), 32, gamma, beta, eps=1e-5))
+    out = ops.groupnorm([to_tokens(x1, dtype), to_tokens(x2, dtype)], B, H * W, 32, gamma.cuda(), beta.cuda(), 1e-5,
+                        silu=True)
+    e, l2 = rel_err(from_tokens(out, B, H, W), ref)
+    assert e < (1e-5 if dtype == torch.float32 else 1e-2), f"{e:.3e} {l2:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 64, 16, 16, 128, 0, 1), (2, 64, 8, 8, 320, 3, 1), (2, 256, 4, 4, 64, 3, 4),
+                                  (3, 64, 3, 3, 64, 0, 1), (2, 640, 2, 2, 128, 0, None)],
+                         ids=["tile_auto", "tile64", "splitk", "straddle", "autosplit"])
+def test_conv_fused_groupnorm_stats(cuda, dtype, case):
+    """The conv epilogue's per-(image, channel) sum / sum of squares equal those of its own output, and a
+    GroupNorm fed with them equals F.group_norm of the conv result."""
+    from madm_amd import ops, packing
+    from madm_amd._lib import lib
+    B, Cin, H, W, Cout, tile, splitk = case
+    kt = ops.k_tile(dtype)
+    x = _q(_gen((B, Cin, H, W), 1), dtype)
+    w = _q(_gen((Cout, Cin, 3, 3), 2) / math.sqrt(Cin * 9), dtype)
+    bias = _gen((Cout,), 3)
+    wp = packing.pack_conv_weight(w, dtype, kt).cuda()
+    st = torch.zeros((B, Cout, 2), device="cuda")
+    lib.madm_debug_set_conv_tile(tile)
+    try:
+        out = ops.conv2d(to_tokens(x, dtype), wp, B, H, W, N=Cout, KH=3, KW=3, pad_t=1, pad_l=1, bias=bias.cuda(),
+                         stats=st, splitk=splitk)
+    finally:
+        lib.madm_debug_set_conv_tile(0)
+    o = out.float().cpu().reshape(B, H * W, Cout)
+    conv_ref = F.conv2d(x, w, bias, padding=1)
+    sums = st.cpu()
+    assert rel_err(sums[..., 0], conv_ref.sum((2, 3)))[0] < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_err(sums[..., 1], (conv_ref ** 2).sum((2, 3)))[0] < (1e-4 if dtype == torch.float32 else 2e-2)
+    gamma, beta = _gen((Cout,), 4), _gen((Cout,), 5)
+    y = ops.groupnorm(out, B, H * W, 32, gamma.cuda(), beta.cuda(), 1e-5, silu=False, stats=[st])
+    ref = F.group_norm(o.permute(0, 2, 1).reshape(B, Cout, H, W), 32, gamma, beta, eps=1e-5)
+    e, l2 = rel_err(from_tokens(y, B, H, W), ref)
+    assert e < (2e-5 if dtype == torch.float32 else 1e-2), f"{e:.3e} {l2:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("MC", [(70, 320), (16, 640), (5, 1280)])
 def test_layernorm(cuda, dtype, MC):
     from madm_amd import ops
@@ -206,6 +258,12 @@ def test_glue_kernels(cuda, dtype):
     assert got[:, 3:].abs().max().item() == 0.0
     mmc = mm.cpu()
     assert abs(mmc[0].item() - ref.min().item()) < 1e-6 and abs(mmc[1].item() - ref.max().item()) < 1e-6
+    # im2col rows of the 3x3 stem: a K = k_tile GEMM over them equals the padded 3x3 conv
+    cols = ops.image_to_im2col3x3(img.cuda(), dtype, kt, 0.5, 0.5, None).float().cpu()
+    unf = F.unfold(ref, 3, padding=1)                       # [B, 27 (c, r, s), HW]
+    unf = unf.reshape(2, 3, 9, -1).permute(0, 3, 2, 1).reshape(2 * 16 * 24, 27)   # k = tap*3 + c
+    assert rel_err(cols[:, :27], unf)[0] < (1e-6 if dtype == torch.float32 else 5e-3)
+    assert cols[:, 27:].abs().max().item() == 0.0
     # nhwc -> nchw
     back = ops.nhwc_to_nchw(t, 2, 3, 16, 24).cpu()
     both = ops.nhwc_to_nchw([t, t], 2, [3, 2], 16, 24).cpu()
