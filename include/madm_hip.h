@@ -90,7 +90,7 @@ typedef struct {
     void* out;            /* [M][ldo] of dtype, M = B*OH*OW */
     int ldo;
     int epilogue;         /* madm_epilogue */
-    float* stats;         /* NULL, or f32 [B][N][2], zeroed by the caller: receives the per-(image, channel)
+    double* stats;        /* NULL, or f64 [B][N][2], zeroed by the caller: receives the per-(image, channel)
                            * sum and sum of squares of the stored output -- the statistics pass of the
                            * GroupNorm that consumes this tensor, fused into the producer's epilogue */
     int splitk;           /* >=1; >1 needs workspace (f32 [splitk][M][N]) */
@@ -111,7 +111,7 @@ void madm_debug_set_conv_tile(int tile);
 /* ---------------------------------------------------------------------------------
  * GroupNorm (32 groups in SD-v1-4; any G dividing Ctot), channels-last.  The normalised tensor has
  * Ctot channels and may be the channel concatenation [source 1 | source 2] (the skip concat of the up
- * blocks, ldm_diffusers.py:370,409).  Statistics are per-(image, channel) f32 (sum, sum of squares)
+ * blocks, ldm_diffusers.py:370,409).  Statistics are per-(image, channel) f64 (sum, sum of squares)
  * arrays `chsums` [B][C][2], one per source: produced either by the epilogue of the conv that wrote
  * the source (madm_conv2d_args.stats) or by madm_groupnorm_stats.
  *   stats: adds x's channel sums into the caller-zeroed chsums[B][C][2].
@@ -123,9 +123,9 @@ void madm_debug_set_conv_tile(int tile);
  * Attention.group_norm (VAE), conv_norm_out + conv_act
  * (ldm_diffusers.py:290,297,299-300,387,435,553,609-610).
  * ------------------------------------------------------------------------------- */
-int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, float* chsums, void* stream);
+int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, double* chsums, void* stream);
 int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int HW, int C,
-                         int c_off, int Ctot, int G, const float* sums1, int C1, const float* sums2,
+                         int c_off, int Ctot, int G, const double* sums1, int C1, const double* sums2,
                          const float* gamma, const float* beta, float eps, int silu, void* stream);
 
 /* LayerNorm over the last dim of [M][C] (BasicTransformerBlock.norm1/2/3, eps 1e-5). */

@@ -16,7 +16,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmP {
     const char* in1; const char* in2; const char* w;
-    const float* bias; const float* rowvec; const char* residual; char* out; float* ws; float* stats;
+    const float* bias; const float* rowvec; const char* residual; char* out; float* ws; double* stats;
     int C1, C2, Ctot, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
     int N, K, M, ldr, ldo, ldrv, epilogue, splitk, tilesN, nk, ld1, ld2;
     unsigned bytes1, bytes2, bytesw;
@@ -57,11 +57,11 @@ __device__ __forceinline__ f32x4 epilogue_store(const IgemmP& p, int m, int n, f
 // slow path of the fused GroupNorm statistics: one atomic pair per element (tiles that straddle images)
 __device__ __forceinline__ void stats_add_elementwise(const IgemmP& p, int m, int n, f32x4 v) {
     const int bi = m / (p.OH * p.OW);
-    float* s = p.stats + ((size_t)bi * p.N + n) * 2;
+    double* s = p.stats + ((size_t)bi * p.N + n) * 2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        atomicAdd(s + 2 * r, v[r]);
-        atomicAdd(s + 2 * r + 1, v[r] * v[r]);
+        atomicAdd(s + 2 * r, (double)v[r]);
+        atomicAdd(s + 2 * r + 1, (double)(v[r] * v[r]));
     }
 }
 
@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 
     // ---- epilogue: lane holds pixel m (lane & 15), channels n .. n+3 (4 * (lane >> 4)) ----
     // Optional fused GroupNorm statistics of the OUTPUT tensor: per-(image, channel) sum and sum of
-    // squares (f32) accumulated in stats[B][N][2] -- the consumer GroupNorm then needs no pass of its own.
+    // squares accumulated in the f64 stats[B][N][2] (f32 partials per block, f64 atomics across blocks: the
+    // result is reproducible to f32 rounding whatever the arrival order) -- the consumer GroupNorm then needs no pass of its own.
     const bool want_stats = p.stats != nullptr && p.splitk == 1;
     int mlast = m0 + BM; if (mlast > p.M) mlast = p.M; mlast -= 1;
     const int img0 = m0 / OHW;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
         __syncthreads();
         for (int c = tid; c < 2 * BN; c += 256) {   // c = channel * 2 + {sum, sumsq}
             const int n = n0 + (c >> 1);
-            if (n < p.N) atomicAdd(p.stats + ((size_t)img0 * p.N + n0) * 2 + c, red[c] + red[2 * BN + c]);
+            if (n < p.N) atomicAdd(p.stats + ((size_t)img0 * p.N + n0) * 2 + c, (double)red[c] + (double)red[2 * BN + c]);
         }
     }
 }
@@ -293,9 +294,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
             const int c = threadIdx.x >> 1, w = threadIdx.x & 1;
             const int nn = blockIdx.x * 64 + c;
             if (nn < p.N) {
-                float a = 0.f;
+                double a = 0.0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) a += red[k][c][w];
+                for (int k = 0; k < 16; ++k) a += (double)red[k][c][w];
                 atomicAdd(p.stats + ((size_t)img0 * p.N + nn) * 2 + w, a);
             }
         }

@@ -8,10 +8,10 @@ namespace {
 // grid (splits, B).  A block owns rows [r0, r1) of image b.  Threads are laid out as
 // (column chunk, row lane); every thread keeps per-channel partial sums of its fixed 16-byte
 // column over its rows, adds them into per-channel LDS sums, and the block adds those to the global
-// f32 chsums[b][c][2] (sum, sum of squares) with contiguous atomics.
+// f64 chsums[b][c][2] (sum, sum of squares) with contiguous atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int HW, int C,
-                                                       int rows_per_block, float* chsums) {
+                                                       int rows_per_block, double* chsums) {
     constexpr int EPC = TT<T>::EPC;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // [C][2]
     const int b = blockIdx.y;
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         }
     }
     __syncthreads();
-    float* dst = chsums + (size_t)b * C * 2;
-    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(dst + c, lds[c]);
+    double* dst = chsums + (size_t)b * C * 2;
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) atomicAdd(dst + c, (double)lds[c]);
 }
 
 // ---- GroupNorm apply (+ optional SiLU) ---------------------------------------------------
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int ldy,
                                                        int HW, int C, int c_off, int Ctot, int G,
-                                                       const float* __restrict__ sums1, int C1,
-                                                       const float* __restrict__ sums2,
+                                                       const double* __restrict__ sums1, int C1,
+                                                       const double* __restrict__ sums2,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int silu) {
     constexpr int EPC = TT<T>::EPC;
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
         double s = 0.0, q = 0.0;
         for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) {
-            const float* src = (ch < C1) ? sums1 + ((size_t)b * C1 + ch) * 2 : sums2 + ((size_t)b * C2 + (ch - C1)) * 2;
-            s += (double)src[0];
-            q += (double)src[1];
+            const double* src = (ch < C1) ? sums1 + ((size_t)b * C1 + ch) * 2 : sums2 + ((size_t)b * C2 + (ch - C1)) * 2;
+            s += src[0];
+            q += src[1];
         }
         const double mean = s / cnt;
         double var = q / cnt - mean * mean;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 
 extern "C" {
 
-int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, float* chsums, void* stream) {
+int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, double* chsums, void* stream) {
     MADM_REQUIRE(x && chsums, "groupnorm_stats: null pointer");
     MADM_REQUIRE(B > 0 && HW > 0 && C > 0, "groupnorm_stats: bad dims B=%d HW=%d C=%d", B, HW, C);
     const int epc = dtype == MADM_BF16 ? 8 : 4;
@@ -193,7 +193,7 @@ int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, float* 
 }
 
 int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int HW, int C, int c_off, int Ctot,
-                         int G, const float* sums1, int C1, const float* sums2, const float* gamma,
+                         int G, const double* sums1, int C1, const double* sums2, const float* gamma,
                          const float* beta, float eps, int silu, void* stream) {
     MADM_REQUIRE(x && y && sums1 && gamma && beta, "groupnorm_apply: null pointer");
     MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && Ctot % G == 0 && c_off >= 0 && c_off + C <= Ctot && ldy >= c_off + C,

@@ -19,7 +19,7 @@ class Tok:
     def __init__(self, t, B, H, W, stats=None):
         assert t.dim() == 2 and t.shape[0] == B * H * W, (t.shape, B, H, W)
         self.t, self.B, self.H, self.W = t, B, H, W
-        # f32 [B, C, 2] per-(image, channel) sum / sum of squares written by the producing kernel's
+        # f64 [B, C, 2] per-(image, channel) sum / sum of squares written by the producing kernel's
         # epilogue (None: a consuming GroupNorm computes them itself)
         self.stats = stats
 

@@ -122,7 +122,7 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     a.ldo = out.stride(0)
     a.epilogue = epilogue
     if stats is not None:
-        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.numel() == B * N * 2
+        assert stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() == B * N * 2
         a.stats = stats.data_ptr()
     a.splitk = 1
     if splitk is None:
@@ -156,7 +156,7 @@ def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=No
 
 
 class StatsArena:
-    """Zero-initialised f32 scratch for the fused GroupNorm statistics: ONE memset per forward instead
+    """Zero-initialised f64 scratch for the fused GroupNorm statistics: ONE memset per forward instead
     of one per layer.  ``reset()`` at the start of a forward allocates (and zeroes) the size the previous
     forward needed; ``take(n)`` hands out slices and falls back to individual allocations on overflow."""
 
@@ -168,7 +168,7 @@ class StatsArena:
 
     def reset(self, device):
         self.need = max(self.need, self.used)
-        self.buf = torch.zeros(self.need, dtype=torch.float32, device=device) if self.need else None
+        self.buf = torch.zeros(self.need, dtype=torch.float64, device=device) if self.need else None
         self.off = 0
         self.used = 0
 
@@ -179,22 +179,22 @@ class StatsArena:
             out = self.buf[self.off:self.off + n]
             self.off += n16
             return out
-        return torch.zeros(n, dtype=torch.float32, device=device)
+        return torch.zeros(n, dtype=torch.float64, device=device)
 
 
 ARENA = StatsArena()
 
 
 def new_chsums(B, C, device):
-    """Zeroed per-(image, channel) statistics buffer [B, C, 2] (f32)."""
+    """Zeroed per-(image, channel) statistics buffer [B, C, 2] (f64)."""
     return ARENA.take(B * C * 2, device).view(B, C, 2)
 
 
 def groupnorm_stats(x, B, HW, chsums):
-    """Adds x's per-(image, channel) sum / sum of squares into the zeroed f32 ``chsums`` [B, C, 2]."""
+    """Adds x's per-(image, channel) sum / sum of squares into the zeroed f64 ``chsums`` [B, C, 2]."""
     _need_cuda(x, chsums)
     assert x.is_contiguous() and x.shape[0] == B * HW
-    assert chsums.dtype == torch.float32 and chsums.is_contiguous() and chsums.numel() == B * x.shape[1] * 2
+    assert chsums.dtype == torch.float64 and chsums.is_contiguous() and chsums.numel() == B * x.shape[1] * 2
     check(lib.madm_groupnorm_stats(dtype_code(x), x.data_ptr(), B, HW, x.shape[1], chsums.data_ptr(), _stream()),
           "madm_groupnorm_stats")
 

@@ -154,7 +154,7 @@ def test_conv_fused_groupnorm_stats(cuda, dtype, case):
     w = _q(_gen((Cout, Cin, 3, 3), 2) / math.sqrt(Cin * 9), dtype)
     bias = _gen((Cout,), 3)
     wp = packing.pack_conv_weight(w, dtype, kt).cuda()
-    st = torch.zeros((B, Cout, 2), device="cuda")
+    st = torch.zeros((B, Cout, 2), device="cuda", dtype=torch.float64)
     lib.madm_debug_set_conv_tile(tile)
     try:
         out = ops.conv2d(to_tokens(x, dtype), wp, B, H, W, N=Cout, KH=3, KW=3, pad_t=1, pad_l=1, bias=bias.cuda(),
@@ -163,7 +163,7 @@ def test_conv_fused_groupnorm_stats(cuda, dtype, case):
         lib.madm_debug_set_conv_tile(0)
     o = out.float().cpu().reshape(B, H * W, Cout)
     conv_ref = F.conv2d(x, w, bias, padding=1)
-    sums = st.cpu()
+    sums = st.float().cpu()
     assert rel_err(sums[..., 0], conv_ref.sum((2, 3)))[0] < (1e-4 if dtype == torch.float32 else 2e-2)
     assert rel_err(sums[..., 1], (conv_ref ** 2).sum((2, 3)))[0] < (1e-4 if dtype == torch.float32 else 2e-2)
     gamma, beta = _gen((Cout,), 4), _gen((Cout,), 5)
