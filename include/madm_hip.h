@@ -105,7 +105,8 @@ int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream);
 /* which kernel instance madm_conv2d_fwd will launch for these arguments:
  * 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64 (used by bench.py to attribute time). */
 int madm_conv2d_pick_tile(const madm_conv2d_args* a);
-/* tuning/debug aid: force the workgroup tile (0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64). */
+/* tuning/debug aid: force the workgroup tile (0 = tuned table then heuristic, -1 = heuristic only,
+ * 1 = 128x128, 2 = 128x64, 3 = 64x64). */
 void madm_debug_set_conv_tile(int tile);
 
 /* ---------------------------------------------------------------------------------

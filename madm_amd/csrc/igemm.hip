@@ -257,38 +257,47 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 }
 
 // sums the split-K slabs and applies the epilogue (+ the fused GroupNorm statistics).
-// Block = 16 channel quads x 16 row lanes, 4 rows per thread: a 64-row x 64-channel output tile.
+// Block = 16 channel quads x 16 rows (one row per thread): a 16-row x 64-channel output tile.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
     __shared__ float red[16][64][2];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int n = (blockIdx.x * 16 + tx) * 4;
-    const int mbase = blockIdx.y * 64;
+    const int mbase = blockIdx.y * 16;
     const int OHW = p.OH * p.OW;
-    int mlast = mbase + 64; if (mlast > p.M) mlast = p.M; mlast -= 1;
+    int mlast = mbase + 16; if (mlast > p.M) mlast = p.M; mlast -= 1;
     const int img0 = mbase / OHW;
     const bool one_image = (mlast / OHW) == img0;
     const bool want_stats = p.stats != nullptr;
-    f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f}, cq = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = mbase + ty + 16 * r;
-        if (m < p.M && n < p.N) {
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int zz = 0; zz < p.splitk; ++zz) {
-                float4 t = *reinterpret_cast<const float4*>(p.ws + ((size_t)zz * p.M + m) * p.N + n);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            v = epilogue_store<T>(p, m, n, v);
-            if (want_stats) {
-                if (one_image) { cs += v; cq += v * v; }
-                else stats_add_elementwise(p, m, n, v);
-            }
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int m = mbase + ty;
+    const bool valid = m < p.M && n < p.N;
+    if (valid) {
+        const float* src = p.ws + (size_t)m * p.N + n;
+        const size_t slab = (size_t)p.M * p.N;
+        int zz = 0;
+        for (; zz + 4 <= p.splitk; zz += 4) {
+            float4 t0 = *reinterpret_cast<const float4*>(src + (size_t)(zz + 0) * slab);
+            float4 t1 = *reinterpret_cast<const float4*>(src + (size_t)(zz + 1) * slab);
+            float4 t2 = *reinterpret_cast<const float4*>(src + (size_t)(zz + 2) * slab);
+            float4 t3 = *reinterpret_cast<const float4*>(src + (size_t)(zz + 3) * slab);
+            v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w;
+            v[0] += t1.x; v[1] += t1.y; v[2] += t1.z; v[3] += t1.w;
+            v[0] += t2.x; v[1] += t2.y; v[2] += t2.z; v[3] += t2.w;
+            v[0] += t3.x; v[1] += t3.y; v[2] += t3.z; v[3] += t3.w;
         }
+        for (; zz < p.splitk; ++zz) {
+            float4 t = *reinterpret_cast<const float4*>(src + (size_t)zz * slab);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        v = epilogue_store<T>(p, m, n, v);
+        if (want_stats && !one_image) stats_add_elementwise(p, m, n, v);
+    } else {
+        v = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (want_stats && one_image) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { red[ty][tx * 4 + r][0] = cs[r]; red[ty][tx * 4 + r][1] = cq[r]; }
+        for (int r = 0; r < 4; ++r) { red[ty][tx * 4 + r][0] = v[r]; red[ty][tx * 4 + r][1] = v[r] * v[r]; }
         __syncthreads();
         if (threadIdx.x < 128) {
             const int c = threadIdx.x >> 1, w = threadIdx.x & 1;
@@ -303,15 +312,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
     }
 }
 
-int g_tile_override = 0;  // 0 = heuristic; 1 = 128x128, 2 = 128x64, 3 = 64x64
+int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1/2/3 = forced tile
 
-int pick_tile(int M, int N) {
-    if (g_tile_override) return g_tile_override;
+// Launch configurations measured on MI355X by tools/tune_conv.py for the layer shapes of the SD-v1-4
+// feature extractor at bs=2, 512x512 (any other shape falls back to the heuristics below).
+struct Tuned { int dtype, M, N, K, KH, tile, splitk; };
+const Tuned g_tuned[] = {
+#include "igemm_tuned.inc"
+    {-1, 0, 0, 0, 0, 0, 0}};
+
+const Tuned* find_tuned(int dtype, int M, int N, int K, int KH) {
+    if (g_tile_override != 0) return nullptr;
+    for (const Tuned* t = g_tuned; t->dtype >= 0; ++t)
+        if (t->dtype == dtype && t->M == M && t->N == N && t->K == K && t->KH == KH) return t;
+    return nullptr;
+}
+
+int heuristic_tile(int M, int N) {
     auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     // prefer the largest tile that still gives the 256 CUs >= ~1.5 waves of work
     if (M >= 128 && N >= 128 && tiles(128, 128) >= 384) return 1;
     if (M >= 128 && tiles(128, 64) >= 256) return 2;
     return 3;
+}
+
+int pick_tile(int dtype, int M, int N, int K, int KH) {
+    if (g_tile_override > 0) return g_tile_override;
+    if (const Tuned* t = find_tuned(dtype, M, N, K, KH)) return t->tile;
+    return heuristic_tile(M, N);
 }
 
 void tile_dims(int t, int& bm, int& bn) {
@@ -371,7 +399,7 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
 template <typename T>
 int launch(const IgemmP& p0, hipStream_t s) {
     IgemmP p = p0;
-    const int t = pick_tile(p.M, p.N);
+    const int t = pick_tile(sizeof(T) == 2 ? MADM_BF16 : MADM_F32, p.M, p.N, p.K, p.KH);
     int bm, bn;
     tile_dims(t, bm, bn);
     p.tilesN = (p.N + bn - 1) / bn;
@@ -383,7 +411,7 @@ int launch(const IgemmP& p0, hipStream_t s) {
     int rc = madm_check_launch("igemm_kernel");
     if (rc) return rc;
     if (p.splitk > 1) {
-        dim3 rgrid((unsigned)((p.N / 4 + 15) / 16), (unsigned)((p.M + 63) / 64));
+        dim3 rgrid((unsigned)((p.N / 4 + 15) / 16), (unsigned)((p.M + 15) / 16));
         splitk_reduce_kernel<T><<<rgrid, 256, 0, s>>>(p);
         rc = madm_check_launch("splitk_reduce_kernel");
     }
@@ -404,16 +432,18 @@ size_t madm_conv2d_workspace_bytes(const madm_conv2d_args* a) {
 
 int madm_conv2d_pick_tile(const madm_conv2d_args* a) {
     if (!a) return 0;
-    return pick_tile(a->B * a->OH * a->OW, a->N);
+    return pick_tile(a->dtype, a->B * a->OH * a->OW, a->N, a->KH * a->KW * (a->C1 + a->C2), a->KH);
 }
 
 int madm_conv2d_suggest_splitk(const madm_conv2d_args* a) {
     if (!a) return 1;
     const int bke = (a->dtype == MADM_BF16) ? 64 : 32;
     const int M = a->B * a->OH * a->OW;
-    const int nk = a->KH * a->KW * (a->C1 + a->C2) / bke;
+    const int Ktot = a->KH * a->KW * (a->C1 + a->C2);
+    const int nk = Ktot / bke;
+    if (const Tuned* t = find_tuned(a->dtype, M, a->N, Ktot, a->KH)) return t->splitk;
     int bm, bn;
-    tile_dims(pick_tile(M, a->N), bm, bn);
+    tile_dims(pick_tile(a->dtype, M, a->N, Ktot, a->KH), bm, bn);
     const long long tiles = (long long)((M + bm - 1) / bm) * ((a->N + bn - 1) / bn);
     if (tiles >= 192 || nk < 8) return 1;
     long long s = (512 + tiles - 1) / tiles;

@@ -10,13 +10,12 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
                                                             int B, int C, int HW, int Cpad, float mean,
                                                             float inv_std, float* minmax) {
     constexpr int EPC = TT<T>::EPC;
-    const size_t total = (size_t)B * HW;
+    const unsigned total = (unsigned)B * (unsigned)HW;
     float lo = INFINITY, hi = -INFINITY;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(idx / HW);
-        const int px = (int)(idx - (size_t)b * HW);
-        T* o = out + idx * Cpad;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int b = (int)(idx / (unsigned)HW);
+        const int px = (int)(idx - (unsigned)b * (unsigned)HW);
+        T* o = out + (size_t)idx * Cpad;
         for (int q = 0; q < Cpad / EPC; ++q) {
             float f[EPC];
 #pragma unroll
@@ -54,34 +53,34 @@ __global__ __launch_bounds__(256) void image_to_im2col_kernel(const float* __res
                                                               int B, int H, int W, int Kpad, float mean,
                                                               float inv_std, float* minmax) {
     constexpr int EPC = TT<T>::EPC;
-    const int CPR = Kpad / EPC;
-    const size_t HW = (size_t)H * W;
-    const size_t total = (size_t)B * HW * CPR;
+    const unsigned CPR = (unsigned)Kpad / EPC;
+    const unsigned HW = (unsigned)H * W;
+    const unsigned total = (unsigned)B * HW * CPR;   // < 2^31 (checked by the launcher)
     float lo = INFINITY, hi = -INFINITY;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int q = (int)(idx % CPR);
-        const size_t pix = idx / CPR;
-        const int b = (int)(pix / HW);
-        const int rem = (int)(pix - (size_t)b * HW);
-        const int y = rem / W, x = rem - y * W;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned q = idx % CPR;
+        const unsigned pix = idx / CPR;
+        const unsigned b = pix / HW;
+        const unsigned rem = pix - b * HW;
+        const int y = (int)(rem / (unsigned)W), x = (int)(rem - (rem / (unsigned)W) * (unsigned)W);
+        const float* ib = img + (size_t)b * 3 * HW;
         float f[EPC];
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
-            const int k = q * EPC + j;
+            const int k = (int)q * EPC + j;
             float v = 0.f;
             if (k < 27) {
                 const int tap = k / 3, c = k - tap * 3;
                 const int r = tap / 3, s2 = tap - r * 3;
                 const int yy = y + r - 1, xx = x + s2 - 1;
                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                    v = (img[((size_t)b * 3 + c) * HW + (size_t)yy * W + xx] - mean) * inv_std;
+                    v = (ib[(unsigned)c * HW + (unsigned)yy * W + xx] - mean) * inv_std;
                     if (tap == 4) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
                 }
             }
             f[j] = v;
         }
-        *reinterpret_cast<uint4*>(out + idx * EPC) = f32_to_chunk<T>(f);
+        *reinterpret_cast<uint4*>(out + (size_t)idx * EPC) = f32_to_chunk<T>(f);
     }
     if (minmax) {
 #pragma unroll
@@ -218,6 +217,7 @@ int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H
     MADM_REQUIRE(std != 0.f, "image_to_im2col3x3: std == 0");
     hipStream_t s = (hipStream_t)stream;
     const size_t total = (size_t)B * H * W * (Kpad / epc);
+    MADM_REQUIRE(total < 0x7fffffffull, "image_to_im2col3x3: tensor too large for 32-bit indexing");
     MADM_DISPATCH_DTYPE(dtype, (image_to_im2col_kernel<T><<<grid_for(total, 8192), 256, 0, s>>>(
                                    img, (T*)out, B, H, W, Kpad, mean, 1.0f / std, minmax)));
     return madm_check_launch("image_to_im2col_kernel");

@@ -94,15 +94,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         shift[c] = beta[c] - gmean[g] * sc;
     }
     __syncthreads();
-    const int CPR = C / EPC;
-    const size_t total = (size_t)HW * CPR;
+    const unsigned CPR = (unsigned)C / EPC;
+    const unsigned total = (unsigned)HW * CPR;   // < 2^31 (checked by the launcher)
     const T* xb = x + (size_t)b * HW * C;
     T* yb = y + (size_t)b * HW * ldy + c_off;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int q = (int)(idx % CPR);
-        const size_t r = idx / CPR;
-        uint4 v = *reinterpret_cast<const uint4*>(xb + idx * EPC);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned r = idx / CPR;
+        const unsigned q = idx - r * CPR;
+        uint4 v = *reinterpret_cast<const uint4*>(xb + (size_t)idx * EPC);
         float f[EPC];
         chunk_to_f32<T>(v, f);
 #pragma unroll
@@ -110,7 +109,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             float t = f[j] * scale[q * EPC + j] + shift[q * EPC + j];
             f[j] = silu ? silu_f(t) : t;
         }
-        *reinterpret_cast<uint4*>(yb + r * ldy + q * EPC) = f32_to_chunk<T>(f);
+        *reinterpret_cast<uint4*>(yb + (size_t)r * ldy + q * EPC) = f32_to_chunk<T>(f);
     }
 }
 
@@ -204,6 +203,7 @@ int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int 
     const size_t shm = ((size_t)2 * C + 2 * G) * sizeof(float);
     MADM_REQUIRE(shm <= 64 * 1024, "groupnorm_apply: C=%d too large", C);
     const size_t total = (size_t)HW * (C / epc);
+    MADM_REQUIRE(total < 0x7fffffffull, "groupnorm_apply: tensor too large for 32-bit indexing");
     size_t strips = (total + 256 * 8 - 1) / (256 * 8);
     const size_t maxstrips = (size_t)(2048 + B - 1) / B;
     if (strips > maxstrips) strips = maxstrips;
