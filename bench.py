@@ -118,18 +118,13 @@ def cpu_baseline(size):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from madm_amd import dist as mdist
+    rank, local_rank, world = mdist.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    dist = mdist.init("nccl", device)   # RCCL: barrier + max-over-ranks only, no data-path collective
 
     from madm_amd.ldm_rocm import LdmRocm
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -188,9 +183,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        elapsed = mdist.max_over_ranks(elapsed, dist, device)
 
     if rank == 0:
         images = args.batch * world * args.steps

@@ -4,6 +4,27 @@
 
 namespace {
 
+// one atomicMin/atomicMax pair per BLOCK (thousands of waves hammering two addresses serialise)
+__device__ __forceinline__ void block_minmax(float lo, float hi, float* minmax) {
+    __shared__ float s_lo[4], s_hi[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_lo[w] = lo; s_hi[w] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 1; i < nw; ++i) { lo = fminf(lo, s_lo[i]); hi = fmaxf(hi, s_hi[i]); }
+        if (lo <= hi) {
+            atomicMin(&minmax[0], lo);
+            atomicMax(&minmax[1], hi);
+        }
+    }
+}
+
 // NCHW f32 image -> channels-last dtype, (x - mean) / std in the first C channels, zeros above.
 template <typename T>
 __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restrict__ img, T* __restrict__ out,
@@ -32,17 +53,7 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
             *reinterpret_cast<uint4*>(o + q * EPC) = f32_to_chunk<T>(f);
         }
     }
-    if (minmax) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = fminf(lo, __shfl_xor(lo, o));
-            hi = fmaxf(hi, __shfl_xor(hi, o));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicMin(&minmax[0], lo);
-            atomicMax(&minmax[1], hi);
-        }
-    }
+    if (minmax) block_minmax(lo, hi, minmax);
 }
 
 // NCHW f32 3-channel image -> im2col rows of the 3x3/pad-1 stem conv: out[pixel][k], k = (r*3+s)*3 + c
@@ -82,17 +93,7 @@ __global__ __launch_bounds__(256) void image_to_im2col_kernel(const float* __res
         }
         *reinterpret_cast<uint4*>(out + (size_t)idx * EPC) = f32_to_chunk<T>(f);
     }
-    if (minmax) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = fminf(lo, __shfl_xor(lo, o));
-            hi = fmaxf(hi, __shfl_xor(hi, o));
-        }
-        if ((threadIdx.x & 63) == 0 && lo <= hi) {
-            atomicMin(&minmax[0], lo);
-            atomicMax(&minmax[1], hi);
-        }
-    }
+    if (minmax) block_minmax(lo, hi, minmax);
 }
 
 template <typename T>
@@ -218,7 +219,7 @@ int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H
     hipStream_t s = (hipStream_t)stream;
     const size_t total = (size_t)B * H * W * (Kpad / epc);
     MADM_REQUIRE(total < 0x7fffffffull, "image_to_im2col3x3: tensor too large for 32-bit indexing");
-    MADM_DISPATCH_DTYPE(dtype, (image_to_im2col_kernel<T><<<grid_for(total, 8192), 256, 0, s>>>(
+    MADM_DISPATCH_DTYPE(dtype, (image_to_im2col_kernel<T><<<grid_for(total, 2048), 256, 0, s>>>(
                                    img, (T*)out, B, H, W, Kpad, mean, 1.0f / std, minmax)));
     return madm_check_launch("image_to_im2col_kernel");
 }

@@ -71,18 +71,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int cpg = Ctot / G;
     const double cnt = (double)HW * (double)cpg;
     const int C2 = Ctot - C1;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    // group fold: 8 lanes per group, each summing every 8th channel of the group (independent loads),
+    // then an xor-shuffle reduction -- a serial per-group loop here would cost cpg dependent HBM/L2 latencies
+    for (int g0 = 0; g0 < G; g0 += 32) {
+        const int g = g0 + (threadIdx.x >> 3), l = threadIdx.x & 7;
         double s = 0.0, q = 0.0;
-        for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) {
-            const double* src = (ch < C1) ? sums1 + ((size_t)b * C1 + ch) * 2 : sums2 + ((size_t)b * C2 + (ch - C1)) * 2;
-            s += src[0];
-            q += src[1];
+        if (g < G) {
+            for (int ch = g * cpg + l; ch < (g + 1) * cpg; ch += 8) {
+                const double* src = (ch < C1) ? sums1 + ((size_t)b * C1 + ch) * 2 : sums2 + ((size_t)b * C2 + (ch - C1)) * 2;
+                s += src[0];
+                q += src[1];
+            }
         }
-        const double mean = s / cnt;
-        double var = q / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        gmean[g] = (float)mean;
-        grstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s += __shfl_xor(s, o);
+            q += __shfl_xor(q, o);
+        }
+        if (g < G && l == 0) {
+            const double mean = s / cnt;
+            double var = q / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gmean[g] = (float)mean;
+            grstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+        }
     }
     __syncthreads();
     gamma += c_off;
