@@ -75,7 +75,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tn = blockIdx.x % p.tilesN, tm = blockIdx.x / p.tilesN;
+    // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a contiguous
+    // range of tiles -- neighbouring output rows re-read the same input lines / weight panels from ITS L2.
+    // (placement only changes speed; the remap is a bijection for any grid size)
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int tn = bid % p.tilesN, tm = bid / p.tilesN;
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
     const int chunk = tid & 7, lrow = tid >> 3;
@@ -125,9 +133,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     const int IWe = p.upsample ? 2 * p.IW : p.IW;
     const int ush = p.upsample ? 1 : 0;
 
-    u32x4 ra[RA], rb[RB];
+    u32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];   // two register stages: loads run two K-tiles ahead
 
-#define IGEMM_LOAD_TILE(kt)                                                                      \
+#define IGEMM_LOAD_TILE(kt, RA_, RB_)                                                                    \
     {                                                                                            \
         const bool first = c0 < p.C1;                                                            \
         const __amdgpu_buffer_rsrc_t rs = first ? rs1 : rs2;                                     \
@@ -138,22 +146,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
             const bool ok = (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;        \
             const unsigned off = (unsigned)(((a_b[i] + (iy >> ush)) * p.IW + (ix >> ush)) * ld + cofs) * \
                                  (unsigned)sizeof(T);                                            \
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);             \
+            RA_[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);            \
         }                                                                                        \
         const unsigned kofs = (unsigned)(kt) * (unsigned)(BKE * sizeof(T));                      \
         _Pragma("unroll") for (int i = 0; i < RB; ++i)                                           \
-            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], kofs, 0);               \
+            RB_[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], kofs, 0);              \
         c0 += BKE;                                                                               \
         if (c0 >= p.Ctot) { c0 = 0; ++ts; if (ts == p.KW) { ts = 0; ++tr; } }                    \
     }
 
-#define IGEMM_STORE_TILE(buf)                                                                    \
+#define IGEMM_STORE_TILE(buf, RA_, RB_)                                                                  \
     {                                                                                            \
         u32x4* sA = reinterpret_cast<u32x4*>(smem) + (buf) * (BM + BN) * 8;                      \
         u32x4* sB = sA + BM * 8;                                                                 \
         const int sw = chunk ^ (lrow & 7);                                                       \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i) sA[(lrow + 32 * i) * 8 + sw] = ra[i];     \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i) sB[(lrow + 32 * i) * 8 + sw] = rb[i];     \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) sA[(lrow + 32 * i) * 8 + sw] = RA_[i];    \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) sB[(lrow + 32 * i) * 8 + sw] = RB_[i];    \
     }
 
     f32x4 acc[MI][NI];
@@ -162,42 +170,49 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Pipeline: LDS buffer (t & 1) holds tile t; register stage 0/1 holds tile t+1; the loads of tile
+    // t+2 are issued before the MFMAs of tile t and get two MFMA phases to land.
     if (kt0 < kt1) {
-        IGEMM_LOAD_TILE(kt0);
-        IGEMM_STORE_TILE(0);
+        IGEMM_LOAD_TILE(kt0, ra0, rb0);
+        if (kt0 + 1 < kt1) IGEMM_LOAD_TILE(kt0 + 1, ra1, rb1);
+        IGEMM_STORE_TILE(0, ra0, rb0);
     }
     __syncthreads();
 
     const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const bool more = (kt + 1 < kt1);
-        // 1. issue the global loads of the next K-tile (they stay in flight during the MFMAs)
-        if (more) IGEMM_LOAD_TILE(kt + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // 2. MFMAs of the current tile
-        {
-            const uint4* sA = smem + cur * (BM + BN) * 8;
-            const uint4* sB = sA + BM * 8;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int c = (fg + 4 * kk) ^ fsw;
-                uint4 af[MI], wf[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) af[i] = sA[(wm * (BM / 2) + i * 16 + frow) * 8 + c];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) wf[j] = sB[(wn * (BN / 2) + j * 16 + frow) * 8 + c];
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) mma16<T>(wf[j], af[i], acc[i][j]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // 3. only now wait for the loads and stage them into the other LDS buffer
-        if (more) IGEMM_STORE_TILE(cur ^ 1);
-        __syncthreads();
+#define IGEMM_COMPUTE(cur)                                                                          \
+    {                                                                                               \
+        const uint4* sA = smem + (cur) * (BM + BN) * 8;                                             \
+        const uint4* sB = sA + BM * 8;                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                          \
+            const int c = (fg + 4 * kk) ^ fsw;                                                      \
+            uint4 af[MI], wf[NI];                                                                   \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                          \
+                af[i] = sA[(wm * (BM / 2) + i * 16 + frow) * 8 + c];                                \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                          \
+                wf[j] = sB[(wn * (BN / 2) + j * 16 + frow) * 8 + c];                                \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                          \
+                _Pragma("unroll") for (int j = 0; j < NI; ++j) mma16<T>(wf[j], af[i], acc[i][j]);   \
+        }                                                                                           \
     }
+    // one step: tile kt is in LDS buffer CUR, tile kt+1 in registers (RS_A/RS_B); tile kt+2 -> (RL_A/RL_B)
+#define IGEMM_STEP(kt, CUR, RL_A, RL_B, RS_A, RS_B)                                                 \
+    {                                                                                               \
+        if ((kt) + 2 < kt1) IGEMM_LOAD_TILE((kt) + 2, RL_A, RL_B);                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        IGEMM_COMPUTE(CUR);                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        if ((kt) + 1 < kt1) IGEMM_STORE_TILE((CUR) ^ 1, RS_A, RS_B);                                \
+        __syncthreads();                                                                            \
+    }
+    int kt = kt0;
+    for (; kt + 1 < kt1; kt += 2) {
+        IGEMM_STEP(kt, 0, ra0, rb0, ra1, rb1);       // loads t+2 -> stage 0 (free), stores stage 1 (t+1)
+        IGEMM_STEP(kt + 1, 1, ra1, rb1, ra0, rb0);   // loads t+3 -> stage 1, stores stage 0 (t+2)
+    }
+    if (kt < kt1) IGEMM_STEP(kt, 0, ra0, rb0, ra1, rb1);
+#undef IGEMM_STEP
+#undef IGEMM_COMPUTE
 #undef IGEMM_LOAD_TILE
 #undef IGEMM_STORE_TILE
 
