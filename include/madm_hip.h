@@ -93,6 +93,14 @@ typedef struct {
     double* stats;        /* NULL, or f64 [B][N][2], zeroed by the caller: receives the per-(image, channel)
                            * sum and sum of squares of the stored output -- the statistics pass of the
                            * GroupNorm that consumes this tensor, fused into the producer's epilogue */
+    /* fused GroupNorm(+SiLU) of the INPUT (3x3 / stride 1 / pad 1 convs on maps >= 8x16 only, see
+     * madm_conv2d_can_fuse_groupnorm): the conv reads RAW sources and applies
+     * y = act(x * gn_scale[b][c] + gn_shift[b][c]) while staging its LDS halo tile, zero padding after the
+     * activation; gn_scale / gn_shift are f32 [B][C1+C2] from madm_groupnorm_finalize, NULL = off;
+     * gn_act: 0 = affine only, 1 = SiLU (ResnetBlock2D norm1/norm2 + nonlinearity, conv_norm_out + conv_act) */
+    const float* gn_scale;
+    const float* gn_shift;
+    int gn_act;
     int splitk;           /* >=1; >1 needs workspace (f32 [splitk][M][N]) */
     void* workspace;
     size_t workspace_bytes;
@@ -102,11 +110,14 @@ size_t madm_conv2d_workspace_bytes(const madm_conv2d_args* a);
 /* heuristic split-K for the MI355X grid (256 CUs); returns 1 when the tile grid already fills it */
 int madm_conv2d_suggest_splitk(const madm_conv2d_args* a);
 int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream);
-/* which kernel instance madm_conv2d_fwd will launch for these arguments:
- * 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64 (used by bench.py to attribute time). */
+/* 1 when these arguments can take gn_scale / gn_shift (the LDS halo-tile 3x3 kernel applies), else 0. */
+int madm_conv2d_can_fuse_groupnorm(const madm_conv2d_args* a);
+/* which kernel instance madm_conv2d_fwd will launch for these arguments: 1 = igemm 128x128,
+ * 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 x128 channels, 5 = halo conv3x3 x64 channels
+ * (used by bench.py to attribute time). */
 int madm_conv2d_pick_tile(const madm_conv2d_args* a);
 /* tuning/debug aid: force the workgroup tile (0 = tuned table then heuristic, -1 = heuristic only,
- * 1 = 128x128, 2 = 128x64, 3 = 64x64). */
+ * 1..5 = the tile codes of madm_conv2d_pick_tile). */
 void madm_debug_set_conv_tile(int tile);
 
 /* ---------------------------------------------------------------------------------
@@ -128,6 +139,12 @@ int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, double*
 int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int HW, int C,
                          int c_off, int Ctot, int G, const double* sums1, int C1, const double* sums2,
                          const float* gamma, const float* beta, float eps, int silu, void* stream);
+
+/* channel sums -> the per-(image, channel) affine of the GroupNorm, scale/shift f32 [B][Ctot]:
+ * y = x * scale + shift == (x - mean_g) * rstd_g * gamma + beta; input of madm_conv2d_args.gn_scale/gn_shift. */
+int madm_groupnorm_finalize(int B, int HW, int Ctot, int G, const double* sums1, int C1,
+                            const double* sums2, const float* gamma, const float* beta, float eps,
+                            float* scale, float* shift, void* stream);
 
 /* LayerNorm over the last dim of [M][C] (BasicTransformerBlock.norm1/2/3, eps 1e-5). */
 int madm_layernorm_fwd(int dtype, const void* x, void* y, int M, int C,

@@ -44,6 +44,7 @@ class Conv2dArgs(ctypes.Structure):
         ("ldo", c_int),
         ("epilogue", c_int),
         ("stats", c_void_p),
+        ("gn_scale", c_void_p), ("gn_shift", c_void_p), ("gn_act", c_int),
         ("splitk", c_int),
         ("workspace", c_void_p),
         ("workspace_bytes", c_size_t),
@@ -67,6 +68,9 @@ SYMBOLS = [
     ("madm_conv2d_workspace_bytes", c_size_t, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_suggest_splitk", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_pick_tile", c_int, [ctypes.POINTER(Conv2dArgs)]),
+    ("madm_conv2d_can_fuse_groupnorm", c_int, [ctypes.POINTER(Conv2dArgs)]),
+    ("madm_groupnorm_finalize", c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_float, c_void_p, c_void_p, c_void_p]),
     ("madm_conv2d_fwd", c_int, [ctypes.POINTER(Conv2dArgs), c_void_p]),
     ("madm_debug_set_conv_tile", None, [c_int]),
     ("madm_groupnorm_stats", c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -1,0 +1,288 @@
+// 3x3 / stride-1 / pad-1 convolution with the INPUT staged as an LDS halo tile, optionally fused with the
+// GroupNorm(+SiLU) that precedes it in ResnetBlock2D (diffusers; reached from
+// /root/reference/modeling/meta_arch/ldm_diffusers.py:290,387,435,609-611).
+//
+// One workgroup (256 threads, 4 waves as 2 x 2) computes an 8 x 16 pixel patch x BN output channels.
+// Per 128-byte channel chunk the (8+2) x (16+2) halo of the patch is brought into LDS ONCE -- with
+// y = silu(x * scale[b][c] + shift[b][c]) applied on the way when the GroupNorm is fused -- and all nine taps
+// read it as shifted views; only the weight tile changes per tap.  Compared with the gather igemm this reads
+// each input element ~1.4x instead of 9x per N-tile and removes the stand-alone GroupNorm-apply pass.
+//   LDS: halo[2][180 px][8 x 16 B] + w[2][BN][8 x 16 B], chunk index XOR-swizzled with (row & 7);
+//   pipeline: weights run two taps ahead in registers (as igemm.hip), the next chunk's halo is loaded at
+//   tap 0 and written to the other halo buffer after tap 8; one barrier per tap.
+// Epilogue (bias, time row, residual, GroupNorm sums of the output, split-K slabs) is shared with igemm.hip.
+#include "igemm_common.hpp"
+
+namespace {
+
+constexpr int TH = 8, TW = 16, HWD = TW + 2, HPIX = (TH + 2) * HWD;  // 180 halo pixels
+
+template <typename T, int EPC>
+__device__ __forceinline__ u32x4 gn_act_chunk(u32x4 raw, const float* sc, const float* sh, int act) {
+    float f[EPC];
+    chunk_to_f32<T>(__builtin_bit_cast(uint4, raw), f);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+        const float t = f[j] * sc[j] + sh[j];
+        f[j] = act ? silu_f(t) : t;
+    }
+    return __builtin_bit_cast(u32x4, f32_to_chunk<T>(f));
+}
+
+template <typename T, int BN, bool FUSE>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int BKE = 8 * EPC;
+    constexpr int MI = 4, NI = BN / 32;     // wave tile: 4 patch rows (64 px) x BN/2 channels
+    constexpr int RB = BN / 32;             // weight rows staged per thread
+    constexpr int HI = (HPIX * 8 + 255) / 256;  // halo chunks staged per thread (6)
+    constexpr int HALO_U4 = HPIX * 8, W_U4 = BN * 8;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    u32x4* halo = reinterpret_cast<u32x4*>(smem_raw);   // [2][HALO_U4]
+    u32x4* wlds = halo + 2 * HALO_U4;                   // [2][W_U4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int cpos = tid & 7, lrow = tid >> 3;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int z = blockIdx.z;
+
+    int bid = blockIdx.x;   // XCD-aware order (see igemm.hip)
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int tn = bid % p.tilesN, tm = bid / p.tilesN;
+    const int n0 = tn * BN;
+    const int b = tm / patchesPerImg;
+    const int pr = tm - b * patchesPerImg;
+    const int py0 = (pr / patchesX) * TH, px0 = (pr % patchesX) * TW;
+
+    // ---- per-thread staging state ----
+    int pixoff[HI], hpos[HI];
+#pragma unroll
+    for (int i = 0; i < HI; ++i) {
+        const int idx = tid + 256 * i;
+        const int h = idx >> 3;
+        const int hy = h / HWD, hx = h - hy * HWD;
+        const int iy = py0 - 1 + hy, ix = px0 - 1 + hx;
+        const bool ok = idx < HPIX * 8 && (unsigned)iy < (unsigned)p.IH && (unsigned)ix < (unsigned)p.IW;
+        pixoff[i] = ok ? (b * p.IH + iy) * p.IW + ix : -1;
+        hpos[i] = idx < HPIX * 8 ? h * 8 + (cpos ^ (h & 7)) : -1;
+    }
+    unsigned wvoff[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        wvoff[i] = (n < p.N) ? (unsigned)(((size_t)n * p.K + cpos * EPC) * sizeof(T)) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in2 ? p.in2 : p.in1), 0,
+                                                                         p.in2 ? p.bytes2 : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.bytesw, 0x00020000);
+
+    const int nchunks = p.Ctot / BKE;
+    const int ck0 = (int)(((long long)nchunks * z) / p.splitk);
+    const int ck1 = (int)(((long long)nchunks * (z + 1)) / p.splitk);
+    const int S = (ck1 - ck0) * 9;
+
+    u32x4 hr[HI], rw0[RB], rw1[RB];
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
+
+#define C3_LOAD_HALO(ck)                                                                            \
+    {                                                                                               \
+        const int c0_ = (ck) * BKE;                                                                 \
+        const bool first_ = c0_ < p.C1;                                                             \
+        const __amdgpu_buffer_rsrc_t rs_ = first_ ? rs1 : rs2;                                      \
+        const int ld_ = first_ ? p.ld1 : p.ld2;                                                     \
+        const int cofs_ = (first_ ? c0_ : c0_ - p.C1) + cpos * EPC;                                 \
+        _Pragma("unroll") for (int i = 0; i < HI; ++i) {                                            \
+            const unsigned off_ = (unsigned)(pixoff[i] * ld_ + cofs_) * (unsigned)sizeof(T);        \
+            hr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, pixoff[i] >= 0 ? off_ : OOB, 0, 0);  \
+        }                                                                                           \
+        if (FUSE) {                                                                                 \
+            const float* gs_ = p.gn_scale + (size_t)b * p.Ctot + c0_ + cpos * EPC;                  \
+            const float* gh_ = p.gn_shift + (size_t)b * p.Ctot + c0_ + cpos * EPC;                  \
+            _Pragma("unroll") for (int j = 0; j < EPC; j += 4) {                                    \
+                const float4 a_ = *reinterpret_cast<const float4*>(gs_ + j);                        \
+                const float4 b_ = *reinterpret_cast<const float4*>(gh_ + j);                        \
+                sc[j] = a_.x; sc[j + 1] = a_.y; sc[j + 2] = a_.z; sc[j + 3] = a_.w;                 \
+                sh[j] = b_.x; sh[j + 1] = b_.y; sh[j + 2] = b_.z; sh[j + 3] = b_.w;                 \
+            }                                                                                       \
+        }                                                                                           \
+    }
+
+#define C3_STORE_HALO(buf)                                                                          \
+    {                                                                                               \
+        u32x4* dst_ = halo + (buf) * HALO_U4;                                                       \
+        _Pragma("unroll") for (int i = 0; i < HI; ++i) {                                            \
+            if (hpos[i] >= 0) {                                                                     \
+                u32x4 v_ = hr[i];                                                                   \
+                if (FUSE) {                                                                         \
+                    v_ = gn_act_chunk<T, EPC>(v_, sc, sh, p.act);                                   \
+                    if (pixoff[i] < 0) v_ = u32x4{0u, 0u, 0u, 0u};   /* the conv pads the ACTIVATED tensor */ \
+                }                                                                                   \
+                dst_[hpos[i]] = v_;                                                                 \
+            }                                                                                       \
+        }                                                                                           \
+    }
+
+    // weight stream: (lck, ltap) = tile the next C3_LOAD_W fetches
+    int lck = ck0, ltap = 0;
+#define C3_LOAD_W(RW_)                                                                              \
+    {                                                                                               \
+        const unsigned kofs_ = (unsigned)(ltap * p.Ctot + lck * BKE) * (unsigned)sizeof(T);         \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                              \
+            RW_[i] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[i], kofs_, 0);                \
+        if (++ltap == 9) { ltap = 0; ++lck; }                                                       \
+    }
+#define C3_STORE_W(buf, RW_)                                                                        \
+    {                                                                                               \
+        u32x4* dst_ = wlds + (buf) * W_U4;                                                          \
+        const int sw_ = cpos ^ (lrow & 7);                                                          \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) dst_[(lrow + 32 * i) * 8 + sw_] = RW_[i];    \
+    }
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (S > 0) {
+        C3_LOAD_HALO(ck0);
+        C3_LOAD_W(rw0);
+        if (S > 1) C3_LOAD_W(rw1);
+        C3_STORE_HALO(0);
+        C3_STORE_W(0, rw0);
+    }
+    __syncthreads();
+
+    int ck = ck0, tap = 0;   // the tile being computed
+#define C3_STEP(s_, CUR, RL_, RS_)                                                                  \
+    {                                                                                               \
+        const bool next_chunk_ = (ck + 1 < ck1);                                                    \
+        if ((s_) + 2 < S) C3_LOAD_W(RL_);                                                           \
+        if (tap == 0 && next_chunk_) C3_LOAD_HALO(ck + 1);                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        {                                                                                           \
+            const u32x4* hsrc_ = halo + ((ck - ck0) & 1) * HALO_U4;                                 \
+            const u32x4* wsrc_ = wlds + (CUR) * W_U4;                                               \
+            const int r_ = tap / 3, sx_ = tap - 3 * r_;                                             \
+            const int hb_ = (wm * 4 + r_) * HWD + frow + sx_;                                       \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                      \
+                const int c_ = fg + 4 * kk;                                                         \
+                uint4 af_[MI], wf_[NI];                                                             \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                    \
+                    const int h_ = hb_ + i * HWD;                                                   \
+                    af_[i] = __builtin_bit_cast(uint4, hsrc_[h_ * 8 + (c_ ^ (h_ & 7))]);            \
+                }                                                                                   \
+                _Pragma("unroll") for (int j = 0; j < NI; ++j)                                      \
+                    wf_[j] = __builtin_bit_cast(uint4, wsrc_[(wn * (BN / 2) + j * 16 + frow) * 8 + (c_ ^ (frow & 7))]); \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i)                                      \
+                    _Pragma("unroll") for (int j = 0; j < NI; ++j) mma16<T>(wf_[j], af_[i], acc[i][j]); \
+            }                                                                                       \
+        }                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+        if ((s_) + 1 < S) C3_STORE_W((CUR) ^ 1, RS_);                                               \
+        if (tap == 8 && next_chunk_) C3_STORE_HALO(((ck - ck0) + 1) & 1);                           \
+        __syncthreads();                                                                            \
+        if (++tap == 9) { tap = 0; ++ck; }                                                          \
+    }
+    int s = 0;
+    for (; s + 1 < S; s += 2) {
+        C3_STEP(s, 0, rw0, rw1);
+        C3_STEP(s + 1, 1, rw1, rw0);
+    }
+    if (s < S) C3_STEP(s, 0, rw0, rw1);
+#undef C3_STEP
+#undef C3_LOAD_W
+#undef C3_STORE_W
+#undef C3_LOAD_HALO
+#undef C3_STORE_HALO
+
+    // ---- epilogue (lane: pixel = patch row wm*4+i, column frow; channels n .. n+3) ----
+    const bool want_stats = p.stats != nullptr && p.splitk == 1;
+    float* red = reinterpret_cast<float*>(smem_raw);   // [2 (wm)][BN][2]
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + fg * 4;
+        f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f}, cq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int oy = py0 + wm * 4 + i, ox = px0 + frow;
+            if (oy < p.OH && ox < p.OW && n < p.N) {
+                const int m = (b * p.OH + oy) * p.OW + ox;
+                if (p.splitk > 1) {
+                    const f32x4 v = acc[i][j];
+                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    const f32x4 v = epilogue_store<T>(p, m, n, acc[i][j]);
+                    if (want_stats) { cs += v; cq += v * v; }
+                }
+            }
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cs[r] += __shfl_xor(cs[r], o);
+                    cq[r] += __shfl_xor(cq[r], o);
+                }
+            }
+            if (frow == 0) {
+                float* dst = red + ((wm * BN) + wn * (BN / 2) + j * 16 + fg * 4) * 2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { dst[2 * r] = cs[r]; dst[2 * r + 1] = cq[r]; }
+            }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        for (int c = tid; c < 2 * BN; c += 256) {
+            const int n = n0 + (c >> 1);
+            if (n < p.N)
+                atomicAdd(p.stats + ((size_t)b * p.N + n0) * 2 + c, (double)red[c] + (double)red[2 * BN + c]);
+        }
+    }
+}
+
+template <typename T, int BN, bool FUSE>
+int launch_one(const IgemmP& p0, hipStream_t s) {
+    IgemmP p = p0;
+    constexpr size_t lds = (size_t)(2 * HPIX * 8 + 2 * BN * 8) * 16;
+    auto kern = conv3x3_halo_kernel<T, BN, FUSE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                madm_set_error("conv3x3: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
+                return MADM_ERR_LAUNCH;
+            }
+        }
+        attr_set = true;
+    }
+    const int patchesX = (p.OW + TW - 1) / TW, patchesY = (p.OH + TH - 1) / TH;
+    p.tilesN = (p.N + BN - 1) / BN;
+    dim3 grid((unsigned)(p.B * patchesX * patchesY * p.tilesN), 1, (unsigned)p.splitk);
+    kern<<<grid, 256, lds, s>>>(p, patchesX, patchesX * patchesY);
+    return madm_check_launch("conv3x3_halo_kernel");
+}
+
+}  // namespace
+
+template <typename T>
+int launch_conv3x3_halo(const IgemmP& p, int bn, hipStream_t s) {
+    const bool fuse = p.gn_scale != nullptr;
+    if (bn == 128) return fuse ? launch_one<T, 128, true>(p, s) : launch_one<T, 128, false>(p, s);
+    return fuse ? launch_one<T, 64, true>(p, s) : launch_one<T, 64, false>(p, s);
+}
+template int launch_conv3x3_halo<float>(const IgemmP&, int, hipStream_t);
+template int launch_conv3x3_halo<bf16_t>(const IgemmP&, int, hipStream_t);

@@ -8,62 +8,9 @@
 // t+1 are issued before the MFMAs of tile t and written to the other buffer after them; one
 // barrier per K-tile.  The MFMA is issued as D = W_frag x A_frag so that every lane ends up with
 // 4 CONSECUTIVE output channels of one pixel: 8/16-byte stores, vector bias / residual loads.
-#include "common.hpp"
+#include "igemm_common.hpp"
 
 namespace {
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-struct IgemmP {
-    const char* in1; const char* in2; const char* w;
-    const float* bias; const float* rowvec; const char* residual; char* out; float* ws; double* stats;
-    int C1, C2, Ctot, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
-    int N, K, M, ldr, ldo, ldrv, epilogue, splitk, tilesN, nk, ld1, ld2;
-    unsigned bytes1, bytes2, bytesw;
-};
-
-// applies bias / time row / GEGLU / residual, stores 4 (2 for GEGLU) outputs, returns the stored values
-template <typename T>
-__device__ __forceinline__ f32x4 epilogue_store(const IgemmP& p, int m, int n, f32x4 v) {
-    if (p.bias) {
-        float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
-    if (p.rowvec) {
-        const int bi = m / (p.OH * p.OW);
-        float4 r = *reinterpret_cast<const float4*>(p.rowvec + (size_t)bi * p.ldrv + n);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-    }
-    if (p.epilogue == MADM_EPI_GEGLU) {
-        float o0 = v[0] * gelu_erf_f(v[1]);
-        float o1 = v[2] * gelu_erf_f(v[3]);
-        const int col = n >> 1;
-        if (p.residual) {
-            const T* r = reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + col;
-            o0 += TT<T>::ld(r); o1 += TT<T>::ld(r + 1);
-        }
-        store2<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + col, o0, o1);
-        return f32x4{o0, o1, 0.f, 0.f};
-    } else {
-        if (p.residual) {
-            f32x4 r = load4<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
-            v += r;
-        }
-        store4<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
-        return v;
-    }
-}
-
-// slow path of the fused GroupNorm statistics: one atomic pair per element (tiles that straddle images)
-__device__ __forceinline__ void stats_add_elementwise(const IgemmP& p, int m, int n, f32x4 v) {
-    const int bi = m / (p.OH * p.OW);
-    double* s = p.stats + ((size_t)bi * p.N + n) * 2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        atomicAdd(s + 2 * r, (double)v[r]);
-        atomicAdd(s + 2 * r + 1, (double)(v[r] * v[r]));
-    }
-}
 
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
@@ -327,7 +274,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
     }
 }
 
-int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1/2/3 = forced tile
+int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..5 = forced tile code
 
 // Launch configurations measured on MI355X by tools/tune_conv.py for the layer shapes of the SD-v1-4
 // feature extractor at bs=2, 512x512 (any other shape falls back to the heuristics below).
@@ -351,15 +298,33 @@ int heuristic_tile(int M, int N) {
     return 3;
 }
 
-int pick_tile(int dtype, int M, int N, int K, int KH) {
-    if (g_tile_override > 0) return g_tile_override;
-    if (const Tuned* t = find_tuned(dtype, M, N, K, KH)) return t->tile;
-    return heuristic_tile(M, N);
+// the LDS halo-tile kernel (conv3x3.hip) handles 3x3 / stride 1 / pad 1 convs on maps of at least one patch
+bool halo_eligible(const madm_conv2d_args* a) {
+    return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && !a->upsample &&
+           a->OH == a->IH && a->OW == a->IW && a->OH >= 8 && a->OW >= 16 && a->epilogue == MADM_EPI_NONE;
+}
+
+// tile codes: 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 BN=128, 5 = halo BN=64
+int pick_tile(const madm_conv2d_args* a) {
+    const int M = a->B * a->OH * a->OW, K = a->KH * a->KW * (a->C1 + a->C2);
+    const bool halo_ok = halo_eligible(a);
+    const int halo_default = (a->N % 128 == 0 || a->N >= 512) ? 4 : 5;
+    if (a->gn_scale) {   // fused GroupNorm exists only in the halo kernel
+        if (g_tile_override == 4 || g_tile_override == 5) return g_tile_override;
+        if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH))
+            if (t->tile >= 4) return t->tile;
+        return halo_default;
+    }
+    if (g_tile_override > 0 && (g_tile_override <= 3 || halo_ok)) return g_tile_override;
+    if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH))
+        if (t->tile <= 3 || halo_ok) return t->tile;
+    if (halo_ok && M >= 2048) return halo_default;
+    return heuristic_tile(M, a->N);
 }
 
 void tile_dims(int t, int& bm, int& bn) {
-    if (t == 1) { bm = 128; bn = 128; }
-    else if (t == 2) { bm = 128; bn = 64; }
+    if (t == 1 || t == 4) { bm = 128; bn = 128; }
+    else if (t == 2 || t == 5) { bm = 128; bn = 64; }
     else { bm = 64; bn = 64; }
 }
 
@@ -383,6 +348,7 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     p.in1 = (const char*)a->in1; p.in2 = (const char*)a->in2; p.w = (const char*)a->w;
     p.bias = a->bias; p.rowvec = a->rowvec; p.residual = (const char*)a->residual;
     p.out = (char*)a->out; p.ws = (float*)a->workspace; p.stats = a->stats;
+    p.gn_scale = nullptr; p.gn_shift = nullptr; p.act = 0;
     MADM_REQUIRE(!a->stats || a->epilogue == MADM_EPI_NONE, "conv2d: fused statistics need the plain epilogue");
     p.C1 = a->C1; p.C2 = a->C2; p.Ctot = a->C1 + a->C2;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW;
@@ -412,18 +378,22 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
 }
 
 template <typename T>
-int launch(const IgemmP& p0, hipStream_t s) {
+int launch(const IgemmP& p0, int t, hipStream_t s) {
     IgemmP p = p0;
-    const int t = pick_tile(sizeof(T) == 2 ? MADM_BF16 : MADM_F32, p.M, p.N, p.K, p.KH);
     int bm, bn;
     tile_dims(t, bm, bn);
-    p.tilesN = (p.N + bn - 1) / bn;
-    const int tilesM = (p.M + bm - 1) / bm;
-    dim3 grid((unsigned)(tilesM * p.tilesN), 1, (unsigned)p.splitk);
-    if (t == 1) igemm_kernel<T, 128, 128><<<grid, 256, 0, s>>>(p);
-    else if (t == 2) igemm_kernel<T, 128, 64><<<grid, 256, 0, s>>>(p);
-    else igemm_kernel<T, 64, 64><<<grid, 256, 0, s>>>(p);
-    int rc = madm_check_launch("igemm_kernel");
+    int rc;
+    if (t >= 4) {
+        rc = launch_conv3x3_halo<T>(p, bn, s);
+    } else {
+        p.tilesN = (p.N + bn - 1) / bn;
+        const int tilesM = (p.M + bm - 1) / bm;
+        dim3 grid((unsigned)(tilesM * p.tilesN), 1, (unsigned)p.splitk);
+        if (t == 1) igemm_kernel<T, 128, 128><<<grid, 256, 0, s>>>(p);
+        else if (t == 2) igemm_kernel<T, 128, 64><<<grid, 256, 0, s>>>(p);
+        else igemm_kernel<T, 64, 64><<<grid, 256, 0, s>>>(p);
+        rc = madm_check_launch("igemm_kernel");
+    }
     if (rc) return rc;
     if (p.splitk > 1) {
         dim3 rgrid((unsigned)((p.N / 4 + 15) / 16), (unsigned)((p.M + 15) / 16));
@@ -447,7 +417,7 @@ size_t madm_conv2d_workspace_bytes(const madm_conv2d_args* a) {
 
 int madm_conv2d_pick_tile(const madm_conv2d_args* a) {
     if (!a) return 0;
-    return pick_tile(a->dtype, a->B * a->OH * a->OW, a->N, a->KH * a->KW * (a->C1 + a->C2), a->KH);
+    return pick_tile(a);
 }
 
 int madm_conv2d_suggest_splitk(const madm_conv2d_args* a) {
@@ -456,9 +426,11 @@ int madm_conv2d_suggest_splitk(const madm_conv2d_args* a) {
     const int M = a->B * a->OH * a->OW;
     const int Ktot = a->KH * a->KW * (a->C1 + a->C2);
     const int nk = Ktot / bke;
-    if (const Tuned* t = find_tuned(a->dtype, M, a->N, Ktot, a->KH)) return t->splitk;
+    const int chosen = pick_tile(a);
+    if (const Tuned* t = find_tuned(a->dtype, M, a->N, Ktot, a->KH))
+        if (t->tile == chosen) return t->splitk;
     int bm, bn;
-    tile_dims(pick_tile(a->dtype, M, a->N, Ktot, a->KH), bm, bn);
+    tile_dims(pick_tile(a), bm, bn);
     const long long tiles = (long long)((M + bm - 1) / bm) * ((a->N + bn - 1) / bn);
     if (tiles >= 192 || nk < 8) return 1;
     long long s = (512 + tiles - 1) / tiles;
@@ -478,9 +450,22 @@ int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream) {
                      "conv2d: split-K %d needs %zu workspace bytes, got %zu", p.splitk, need,
                      a->workspace_bytes);
     }
+    const int t = pick_tile(a);
+    if (a->gn_scale) {
+        MADM_REQUIRE(a->gn_shift && halo_eligible(a),
+                     "conv2d: fused GroupNorm needs gn_shift and a 3x3 / stride-1 / pad-1 conv on a map of at least 8x16 "
+                     "(use madm_groupnorm_apply otherwise; madm_conv2d_can_fuse_groupnorm tells)");
+        p.gn_scale = a->gn_scale; p.gn_shift = a->gn_shift; p.act = a->gn_act;
+    }
+    if (t >= 4) {   // the halo kernel splits K by whole channel chunks
+        const int nchunks = p.Ctot / ((a->dtype == MADM_BF16) ? 64 : 32);
+        if (p.splitk > nchunks) p.splitk = nchunks;
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (a->dtype == MADM_F32) return launch<float>(p, s);
-    return launch<bf16_t>(p, s);
+    if (a->dtype == MADM_F32) return launch<float>(p, t, s);
+    return launch<bf16_t>(p, t, s);
 }
+
+int madm_conv2d_can_fuse_groupnorm(const madm_conv2d_args* a) { return a && halo_eligible(a) ? 1 : 0; }
 
 }  // extern "C"

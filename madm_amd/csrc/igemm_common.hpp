@@ -1,0 +1,63 @@
+// Shared by igemm.hip (gather implicit GEMM) and conv3x3.hip (LDS halo-tile 3x3 conv): launch
+// parameters, the common epilogue and the split-K reduction interface.
+#pragma once
+#include "common.hpp"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct IgemmP {
+    const char* in1; const char* in2; const char* w;
+    const float* bias; const float* rowvec; const char* residual; char* out; float* ws; double* stats;
+    int C1, C2, Ctot, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
+    int N, K, M, ldr, ldo, ldrv, epilogue, splitk, tilesN, nk, ld1, ld2;
+    unsigned bytes1, bytes2, bytesw;
+    // halo-tile 3x3 conv only: fused GroupNorm(+SiLU) of the INPUT, y = act(x * gn_scale[b][c] + gn_shift[b][c])
+    const float* gn_scale; const float* gn_shift; int act;
+};
+
+// applies bias / time row / GEGLU / residual, stores 4 (2 for GEGLU) outputs, returns the stored values
+template <typename T>
+__device__ __forceinline__ f32x4 epilogue_store(const IgemmP& p, int m, int n, f32x4 v) {
+    if (p.bias) {
+        float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.rowvec) {
+        const int bi = m / (p.OH * p.OW);
+        float4 r = *reinterpret_cast<const float4*>(p.rowvec + (size_t)bi * p.ldrv + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    if (p.epilogue == MADM_EPI_GEGLU) {
+        float o0 = v[0] * gelu_erf_f(v[1]);
+        float o1 = v[2] * gelu_erf_f(v[3]);
+        const int col = n >> 1;
+        if (p.residual) {
+            const T* r = reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + col;
+            o0 += TT<T>::ld(r); o1 += TT<T>::ld(r + 1);
+        }
+        store2<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + col, o0, o1);
+        return f32x4{o0, o1, 0.f, 0.f};
+    } else {
+        if (p.residual) {
+            f32x4 r = load4<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
+            v += r;
+        }
+        store4<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+        return v;
+    }
+}
+
+// slow path of the fused GroupNorm statistics: one atomic pair per element (tiles that straddle images)
+__device__ __forceinline__ void stats_add_elementwise(const IgemmP& p, int m, int n, f32x4 v) {
+    const int bi = m / (p.OH * p.OW);
+    double* s = p.stats + ((size_t)bi * p.N + n) * 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        atomicAdd(s + 2 * r, (double)v[r]);
+        atomicAdd(s + 2 * r + 1, (double)(v[r] * v[r]));
+    }
+}
+
+
+// conv3x3.hip: stride-1 / pad-1 3x3 conv with the input staged as an LDS halo tile (bn = 128 or 64)
+template <typename T> int launch_conv3x3_halo(const IgemmP& p, int bn, hipStream_t s);

@@ -125,6 +125,51 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// ---- GroupNorm finalize: channel sums -> per-(image, channel) affine (scale, shift) ----------------
+// y = x * scale + shift == (x - mean_g) * rstd_g * gamma + beta; consumed by the conv that fuses the
+// normalisation into its LDS halo load (conv3x3.hip).  grid = B blocks.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(int HW, int Ctot, int G, const double* __restrict__ sums1,
+                                                          int C1, const double* __restrict__ sums2,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float gmean[256], grstd[256];
+    const int b = blockIdx.x;
+    const int cpg = Ctot / G;
+    const double cnt = (double)HW * (double)cpg;
+    const int C2 = Ctot - C1;
+    for (int g0 = 0; g0 < G; g0 += 32) {
+        const int g = g0 + (threadIdx.x >> 3), l = threadIdx.x & 7;
+        double s = 0.0, q = 0.0;
+        if (g < G) {
+            for (int ch = g * cpg + l; ch < (g + 1) * cpg; ch += 8) {
+                const double* src = (ch < C1) ? sums1 + ((size_t)b * C1 + ch) * 2 : sums2 + ((size_t)b * C2 + (ch - C1)) * 2;
+                s += src[0];
+                q += src[1];
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s += __shfl_xor(s, o);
+            q += __shfl_xor(q, o);
+        }
+        if (g < G && l == 0) {
+            const double mean = s / cnt;
+            double var = q / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gmean[g] = (float)mean;
+            grstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Ctot; c += blockDim.x) {
+        const int g = c / cpg;
+        const float sc = grstd[g] * gamma[c];
+        scale[(size_t)b * Ctot + c] = sc;
+        shift[(size_t)b * Ctot + c] = beta[c] - gmean[g] * sc;
+    }
+}
+
 // ---- LayerNorm: one wave per row, row held in registers (C <= 64 * MAXCH * EPC) ---------
 template <typename T, int MAXCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, int M,
@@ -225,6 +270,16 @@ int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int 
     MADM_DISPATCH_DTYPE(dtype, (gn_apply_kernel<T><<<grid, 256, shm, s>>>((const T*)x, (T*)y, ldy, HW, C, c_off, Ctot, G,
                                                                         sums1, C1, sums2, gamma, beta, eps, silu)));
     return madm_check_launch("gn_apply_kernel");
+}
+
+int madm_groupnorm_finalize(int B, int HW, int Ctot, int G, const double* sums1, int C1, const double* sums2,
+                            const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                            void* stream) {
+    MADM_REQUIRE(sums1 && gamma && beta && scale && shift, "groupnorm_finalize: null pointer");
+    MADM_REQUIRE(B > 0 && HW > 0 && G > 0 && G <= 256 && Ctot % G == 0 && C1 > 0 && C1 <= Ctot && (C1 == Ctot || sums2),
+                 "groupnorm_finalize: bad dims");
+    gn_finalize_kernel<<<B, 256, 0, (hipStream_t)stream>>>(HW, Ctot, G, sums1, C1, sums2, gamma, beta, eps, scale, shift);
+    return madm_check_launch("gn_finalize_kernel");
 }
 
 int madm_layernorm_fwd(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta,

@@ -115,10 +115,29 @@ class Conv2d(_Packed):
         p = self.padding
         return (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
 
-    def forward(self, x, x2=None, upsample=False, rowvec=None, residual=None, out=None, stats=True):
+    def forward(self, x, x2=None, upsample=False, rowvec=None, residual=None, out=None, stats=True, norm=None,
+                act=True):
         """x (and optional x2 = channel-concatenated second source) are Tok; returns Tok.  ``stats``:
-        also emit the GroupNorm statistics of the output from the epilogue (Tok.stats)."""
+        also emit the GroupNorm statistics of the output from the epilogue (Tok.stats).  ``norm``: a
+        GroupNorm module applied (with SiLU when ``act``) to [x | x2] before the conv -- folded into the
+        conv's LDS halo load when the 3x3 halo kernel applies, a separate pass otherwise."""
         dtype = x.t.dtype
+        gn = None
+        if norm is not None:
+            if ops.can_fuse_groupnorm(x.H, x.W, self.kernel_size, self.stride, self.padding, self.asym_pad, upsample):
+                srcs = [x] if x2 is None else [x, x2]
+                sts = []
+                for s_ in srcs:
+                    if s_.stats is None:
+                        s_.stats = ops.new_chsums(s_.B, s_.C, s_.t.device)
+                        ops.groupnorm_stats(s_.t, s_.B, s_.HW, s_.stats)
+                    sts.append(s_.stats)
+                scale, shift = ops.groupnorm_finalize(sts, x.B, x.HW, norm.num_groups, norm.weight.detach(),
+                                                      norm.bias.detach(), norm.eps)
+                gn = (scale, shift, act)
+            else:
+                x = norm(x, silu=act, x2=x2)
+                x2 = None
         splits = None
         if x2 is not None:
             splits = [x.C, x2.C]
@@ -131,7 +150,8 @@ class Conv2d(_Packed):
                        KH=self.kernel_size, KW=self.kernel_size, stride=self.stride, pad_t=pad, pad_l=pad,
                        OH=OH, OW=OW, upsample=upsample, bias=b, rowvec=rowvec,
                        residual=None if residual is None else residual.t, out=out,
-                       alg_nk=(self.out_channels, self.kernel_size * self.kernel_size * self.in_channels), stats=st)
+                       alg_nk=(self.out_channels, self.kernel_size * self.kernel_size * self.in_channels), stats=st,
+                       gn=gn)
         return Tok(o, x.B, OH, OW, st)
 
 

@@ -46,7 +46,29 @@ _workspaces = {}
 # appends (kernel name, algorithmic FLOPs, start event, end event) recorded on the launch stream.
 PROFILE = None
 CAPTURE = None   # tools/tune_conv.py: when a list, conv2d appends (args struct, tensors kept alive, desc)
-_TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64"}
+_TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64", 4: "conv3x3_halo_x128", 5: "conv3x3_halo_x64"}
+FUSE_GN = True   # fold GroupNorm(+SiLU) into eligible 3x3 convs (debug switch)
+
+
+def can_fuse_groupnorm(IH, IW, KH, stride, pad, asym_pad, upsample):
+    """Mirror of madm_conv2d_can_fuse_groupnorm (the LDS halo-tile 3x3 kernel applies)."""
+    return FUSE_GN and KH == 3 and stride == 1 and pad == 1 and not asym_pad and not upsample and IH >= 8 and IW >= 16
+
+
+def groupnorm_finalize(stats, B, HW, G, gamma, beta, eps):
+    """Channel sums of one or two concatenated sources -> (scale, shift) f32 [B, Ctot] with
+    x * scale + shift == GroupNorm(x) (input of conv2d(..., gn=...))."""
+    _need_cuda(gamma, beta, *stats)
+    C1 = stats[0].shape[1]
+    Ctot = sum(st.shape[1] for st in stats)
+    assert gamma.numel() == Ctot and all(st.dtype == torch.float64 and st.is_contiguous() for st in stats)
+    scale = torch.empty((B, Ctot), dtype=torch.float32, device=gamma.device)
+    shift = torch.empty((B, Ctot), dtype=torch.float32, device=gamma.device)
+    check(lib.madm_groupnorm_finalize(B, HW, Ctot, G, stats[0].data_ptr(), C1,
+                                      stats[1].data_ptr() if len(stats) > 1 else None, gamma.data_ptr(),
+                                      beta.data_ptr(), float(eps), scale.data_ptr(), shift.data_ptr(), _stream()),
+          "madm_groupnorm_finalize")
+    return scale, shift
 
 
 class _Prof:
@@ -78,7 +100,7 @@ def _workspace(nbytes, device):
 
 def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
            upsample=False, bias=None, rowvec=None, residual=None, epilogue=EPI_NONE, out=None,
-           splitk=None, alg_nk=None, stats=None):
+           splitk=None, alg_nk=None, stats=None, gn=None):
     """Implicit-GEMM conv / linear.  x1: [B*IH*IW, C1] dense; x2 optional second source (concat);
     w: packed [N, KH*KW*(C1+C2)]; returns out [B*OH*OW, N] (N/2 columns for GEGLU)."""
     _need_cuda(x1, w, x2, bias, rowvec, residual, out)
@@ -125,6 +147,11 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() == B * N * 2
         a.stats = stats.data_ptr()
+    if gn is not None:   # (scale [B, C1+C2] f32, shift, act): GroupNorm(+SiLU) of the input fused into the conv
+        gs, gh, act = gn
+        assert gs.dtype == torch.float32 and gh.dtype == torch.float32 and gs.is_contiguous() and gh.is_contiguous()
+        assert gs.numel() == B * (C1 + C2) and gh.numel() == gs.numel()
+        a.gn_scale, a.gn_shift, a.gn_act = gs.data_ptr(), gh.data_ptr(), 1 if act else 0
     a.splitk = 1
     if splitk is None:
         splitk = lib.madm_conv2d_suggest_splitk(ctypes.byref(a))
@@ -136,15 +163,16 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
     if CAPTURE is not None:
-        CAPTURE.append((a, (x1, x2, w, bias, rowvec, residual, out, stats, ws),
+        CAPTURE.append((a, (x1, x2, w, bias, rowvec, residual, out, stats, ws, gn),
                         f"M{M} N{N} K{KH * KW * (C1 + C2)} k{KH} s{stride}{' up' if upsample else ''}"
-                        f"{' cat' if C2 else ''}{' st' if stats is not None else ''}"))
+                        f"{' cat' if C2 else ''}{' st' if stats is not None else ''}{' gn' if gn is not None else ''}"))
     if PROFILE is None:
         check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     else:
         an, ak = alg_nk if alg_nk is not None else (N, KH * KW * (C1 + C2))
         name = _TILE_NAMES[lib.madm_conv2d_pick_tile(ctypes.byref(a))] + ("_f32" if x1.dtype == torch.float32 else "_bf16")
-        desc = f"M{M} N{N} K{KH * KW * (C1 + C2)} k{KH} s{stride}{' up' if upsample else ''} sk{a.splitk}"
+        desc = (f"M{M} N{N} K{KH * KW * (C1 + C2)} k{KH} s{stride}{' up' if upsample else ''}"
+                f"{' gn' if gn is not None else ''} sk{a.splitk}")
         with _Prof(name, 2.0 * M * an * ak, desc):
             check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     return out

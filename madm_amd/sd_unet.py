@@ -234,18 +234,12 @@ class ResnetBlock2D(nn.Module):
     def forward(self, x, temb_row=None, skip=None):
         """x (+ optional skip = second concat source) -> Tok.  ``temb_row``: f32 [B, Cout] =
         time_emb_proj(silu(emb)) (computed for all resnets at once by the UNet)."""
-        if skip is None:
-            h = self.norm1(x, silu=True)
-            h = self.conv1(h, rowvec=temb_row)
-            res = x if self.conv_shortcut is None else self.conv_shortcut(x, stats=False)
+        h = self.conv1(x, x2=skip, norm=self.norm1, rowvec=temb_row)   # GN + SiLU + conv (+ time row)
+        if self.conv_shortcut is None:
+            res = x
         else:
-            # GroupNorm over the concatenated channels: the concat exists only as the normalised
-            # copy written by the two-source GN; the 1x1 shortcut reads the two sources directly.
-            h = self.norm1(x, silu=True, x2=skip)
-            h = self.conv1(h, rowvec=temb_row)
-            res = self.conv_shortcut(x, x2=skip, stats=False)
-        h = self.norm2(h, silu=True)
-        return self.conv2(h, residual=res)
+            res = self.conv_shortcut(x, x2=skip, stats=False)   # 1x1 over the raw (concatenated) input
+        return self.conv2(h, norm=self.norm2, residual=res)
 
 
 class Downsample2D(nn.Module):
@@ -490,5 +484,4 @@ class UNet2DConditionModel(nn.Module):
                 for u in blk.upsamplers:
                     h = u(h)
         assert len(taps) == len(unet_block_indices)
-        h = self.conv_norm_out(h, silu=True)
-        return self.conv_out(h, stats=False), taps
+        return self.conv_out(h, norm=self.conv_norm_out, stats=False), taps

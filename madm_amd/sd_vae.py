@@ -154,8 +154,6 @@ class AutoencoderKL(_Packed):
                 for d in blk.downsamplers:
                     h = d(h)
         h = enc.mid_block(h)
-        h = enc.conv_norm_out(h, silu=True)
-
         def build():
             W = enc.conv_out.weight.detach().double()            # [8, 512, 3, 3]
             b = enc.conv_out.bias.detach().double()
@@ -166,7 +164,17 @@ class AutoencoderKL(_Packed):
             return packing.pack_conv_weight(Wf, dtype, ops.k_tile(dtype)), bf
 
         wp, bp = self._cache_get((dtype, "enc_out"), build)
-        o = ops.conv2d(h.t, wp, h.B, h.H, h.W, N=wp.shape[0], KH=3, KW=3, pad_t=1, pad_l=1, bias=bp)
+        gn = None
+        if ops.can_fuse_groupnorm(h.H, h.W, 3, 1, 1, False, False):
+            if h.stats is None:
+                h.stats = ops.new_chsums(h.B, h.C, h.t.device)
+                ops.groupnorm_stats(h.t, h.B, h.HW, h.stats)
+            no = enc.conv_norm_out
+            gn = (*ops.groupnorm_finalize([h.stats], h.B, h.HW, no.num_groups, no.weight.detach(), no.bias.detach(),
+                                          no.eps), True)
+        else:
+            h = enc.conv_norm_out(h, silu=True)
+        o = ops.conv2d(h.t, wp, h.B, h.H, h.W, N=wp.shape[0], KH=3, KW=3, pad_t=1, pad_l=1, bias=bp, gn=gn)
         return h.like(o), taps
 
     # ---- decoder: vae_decoder (ldm_diffusers.py:314-346) ----

@@ -39,6 +39,13 @@ CONV_CASES = [
     ("1x1", 2, [128], 8, 8, 64, 1, 1, "none", False, 0, 1),
     ("3x3_tiny_cin", 1, [3], 16, 16, 128, 3, 1, "same", False, 0, 1),
     ("3x3_tiny_cout", 2, [64], 8, 8, 4, 3, 1, "same", False, 0, 1),
+    # LDS halo-tile kernel (tile codes 4 = x128 channels, 5 = x64), full / ragged patches, concat, split-K
+    ("halo128", 2, [128], 16, 32, 256, 3, 1, "same", False, 4, 1),
+    ("halo64", 2, [64], 16, 16, 320, 3, 1, "same", False, 5, 1),
+    ("halo_ragged", 1, [64], 13, 21, 192, 3, 1, "same", False, 4, 1),
+    ("halo_concat", 2, [128, 64], 8, 16, 128, 3, 1, "same", False, 5, 1),
+    ("halo_splitk", 2, [256], 8, 16, 64, 3, 1, "same", False, 5, 2),
+    ("halo_auto", 1, [64], 64, 64, 128, 3, 1, "same", False, 0, None),
 ]
 
 
@@ -171,6 +178,47 @@ def test_conv_fused_groupnorm_stats(cuda, dtype, case):
     ref = F.group_norm(o.permute(0, 2, 1).reshape(B, Cout, H, W), 32, gamma, beta, eps=1e-5)
     e, l2 = rel_err(from_tokens(y, B, H, W), ref)
     assert e < (2e-5 if dtype == torch.float32 else 1e-2), f"{e:.3e} {l2:.3e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, [128], 16, 32, 128, True, 4), (2, [320], 16, 16, 320, True, 5),
+                                  (1, [64], 11, 19, 64, False, 5), (2, [128, 64], 8, 16, 192, True, 5),
+                                  (2, [1280, 640], 8, 16, 64, True, 5)],
+                         ids=["x128", "x64", "ragged_affine", "concat", "concat_straddle"])
+def test_conv_fused_groupnorm_input(cuda, dtype, case):
+    """conv3x3(silu(GroupNorm([x | skip]))) with the normalisation folded into the conv's LDS halo load
+    (statistics -> madm_groupnorm_finalize -> gn_scale/gn_shift) equals the unfused torch composition,
+    including the zero padding applied AFTER the activation."""
+    from madm_amd import ops, packing
+    from madm_amd._lib import lib
+    B, cins, H, W, Cout, act, tile = case
+    kt = ops.k_tile(dtype)
+    Cin = sum(cins)
+    xs = [_q(_gen((B, c, H, W), 20 + i) * (1.0 + i) + 0.5 * i, dtype) for i, c in enumerate(cins)]
+    gamma, beta = 1.0 + 0.2 * _gen((Cin,), 2), 0.3 * _gen((Cin,), 3)
+    w = _q(_gen((Cout, Cin, 3, 3), 4) / math.sqrt(Cin * 9), dtype)
+    bias = _gen((Cout,), 5)
+    h = F.group_norm(torch.cat(xs, 1), 32, gamma, beta, eps=1e-5)
+    if act:
+        h = F.silu(h)
+    ref = F.conv2d(h, w, bias, padding=1)
+    toks = [to_tokens(x, dtype) for x in xs]
+    sts = []
+    for t in toks:
+        st = torch.zeros((B, t.shape[1], 2), dtype=torch.float64, device="cuda")
+        ops.groupnorm_stats(t, B, H * W, st)
+        sts.append(st)
+    scale, shift = ops.groupnorm_finalize(sts, B, H * W, 32, gamma.cuda(), beta.cuda(), 1e-5)
+    wp = packing.pack_conv_weight(w, dtype, kt, splits=cins).cuda()
+    lib.madm_debug_set_conv_tile(tile)
+    try:
+        out = ops.conv2d(toks[0], wp, B, H, W, N=Cout, x2=toks[1] if len(toks) > 1 else None, KH=3, KW=3, pad_t=1,
+                         pad_l=1, bias=bias.cuda(), gn=(scale, shift, act))
+    finally:
+        lib.madm_debug_set_conv_tile(0)
+    e, l2 = rel_err(from_tokens(out, B, H, W), ref)
+    # bf16: the fused path rounds the activated input once to bf16 exactly like the unfused one
+    assert e < (3e-5 if dtype == torch.float32 else 2e-2), f"{e:.3e} {l2:.3e}"
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
