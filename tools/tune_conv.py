@@ -48,9 +48,14 @@ def main():
         K = a0.KH * a0.KW * (a0.C1 + a0.C2)
         nk = K // (64 if args.dtype == "bf16" else 32)
         results = {}
-        for tile in (1, 2, 3):
+        halo_ok = bool(lib.madm_conv2d_can_fuse_groupnorm(ctypes.byref(a0)))
+        tiles = (4, 5) if a0.gn_scale else ((1, 2, 3, 4, 5) if halo_ok else (1, 2, 3))
+        nchunks = (a0.C1 + a0.C2) // (64 if args.dtype == "bf16" else 32)
+        for tile in tiles:
             for sk in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
                 if sk > 1 and (sk > nk // 2):
+                    continue
+                if tile >= 4 and sk > nchunks:
                     continue
                 if sk > 1 and M * a0.N * 4 * sk > ws.numel():
                     continue
@@ -94,7 +99,7 @@ def main():
     print("\n// ---- rows for igemm_tuned.inc: {dtype, M, N, K, KH, tile, splitk}")
     seen = set()
     dt = 1 if args.dtype == "bf16" else 0
-    for r in sorted(rows, key=lambda r: (r[10], r[11], r[12])):
+    for r in sorted(rows, key=lambda r: (r[10], r[11], r[12], 0 if " gn" in r[1] else 1)):
         key = (r[10], r[11], r[12], r[13])
         if key in seen:
             continue
