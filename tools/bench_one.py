@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Runs ONE conv shape repeatedly (for rocprofv3 --pmc passes and quick A/B timing).
+python tools/bench_one.py --M-hw 512 512 --B 2 --cin 128 --cout 128 --tile 4 [--gn] [--reps 20]"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hw", type=int, nargs=2, default=[512, 512])
+    ap.add_argument("--B", type=int, default=2)
+    ap.add_argument("--cin", type=int, default=128)
+    ap.add_argument("--cout", type=int, default=128)
+    ap.add_argument("--k", type=int, default=3)
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--splitk", type=int, default=1)
+    ap.add_argument("--gn", action="store_true")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16")
+    args = ap.parse_args()
+    from madm_amd import ops
+    from madm_amd._lib import lib
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    H, W = args.hw
+    B, Cin, Cout, k = args.B, args.cin, args.cout, args.k
+    x = torch.randn((B * H * W, Cin), device="cuda").to(dtype)
+    w = (torch.randn((Cout, k * k * Cin), device="cuda") / math.sqrt(k * k * Cin)).to(dtype)
+    bias = torch.randn(Cout, device="cuda")
+    gn = None
+    if args.gn:
+        gn = (torch.rand((B, Cin), device="cuda") + 0.5, torch.randn((B, Cin), device="cuda") * 0.1, True)
+    st = torch.zeros((B, Cout, 2), dtype=torch.float64, device="cuda")
+    lib.madm_debug_set_conv_tile(args.tile)
+
+    def run():
+        return ops.conv2d(x, w, B, H, W, N=Cout, KH=k, KW=k, pad_t=k // 2, pad_l=k // 2, bias=bias, stats=st, gn=gn,
+                          splitk=args.splitk)
+
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / args.reps * 1e3
+    fl = 2.0 * B * H * W * Cout * k * k * Cin
+    print(f"tile {args.tile} M{B * H * W} N{Cout} K{k * k * Cin}: {us:.1f} us  {fl / us / 1e6:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
