@@ -81,14 +81,17 @@ typedef struct {
     int pad_t, pad_l;     /* bottom/right padding is implied by OH/OW (zero fill) */
     int upsample;         /* 1: nearest 2x upsample of the sources before the conv */
     const void* w;        /* [N][K] of dtype, K = KH*KW*(C1+C2) */
+    int ldw;              /* row stride of w in elements; 0 = dense (K) */
     int N;                /* output channels; multiple of 4 */
     const float* bias;    /* [N] or NULL */
     const float* rowvec;  /* [B][ldrv] or NULL: per-image row added to every pixel */
     int ldrv;             /* row stride of rowvec in floats (>= N, multiple of 4) */
     const void* residual; /* [M][ldr] of dtype or NULL; added after the epilogue */
     int ldr;
-    void* out;            /* [M][ldo] of dtype, M = B*OH*OW */
+    void* out;            /* [M][ldo] of dtype (f32 when out_f32), M = B*OH*OW */
     int ldo;
+    int out_f32;          /* 1: store f32 whatever the compute dtype (attention logits of the GEMM-based
+                           * VAE mid-block attention); plain epilogue, no residual */
     int epilogue;         /* madm_epilogue */
     double* stats;        /* NULL, or f64 [B][N][2], zeroed by the caller: receives the per-(image, channel)
                            * sum and sum of squares of the stored output -- the statistics pass of the
@@ -167,6 +170,12 @@ typedef struct {
     float scale;
 } madm_attention_args;
 int madm_attention_fwd(const madm_attention_args* a, void* stream);
+
+/* p[r][:] = softmax(scale * s[r][:]) over L columns: f32 logits [rows][lds] -> dtype [rows][ldp].  With two
+ * madm_conv2d_fwd GEMMs (S = Q K^T with out_f32, O = P V) this is the single-head d = 512, L = 4096
+ * attention of the VAE mid block (ldm_diffusers.py:297), where GEMM tiles beat the flash kernel. */
+int madm_softmax_rows(int dtype, const float* s, void* p, int rows, int L, int lds, int ldp,
+                      float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Small glue kernels of LdmDiffusers.forward (ldm_diffusers.py:143-217).

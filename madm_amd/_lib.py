@@ -34,6 +34,7 @@ class Conv2dArgs(ctypes.Structure):
         ("pad_t", c_int), ("pad_l", c_int),
         ("upsample", c_int),
         ("w", c_void_p),
+        ("ldw", c_int),
         ("N", c_int),
         ("bias", c_void_p),
         ("rowvec", c_void_p),
@@ -42,6 +43,7 @@ class Conv2dArgs(ctypes.Structure):
         ("ldr", c_int),
         ("out", c_void_p),
         ("ldo", c_int),
+        ("out_f32", c_int),
         ("epilogue", c_int),
         ("stats", c_void_p),
         ("gn_scale", c_void_p), ("gn_shift", c_void_p), ("gn_act", c_int),
@@ -78,6 +80,7 @@ SYMBOLS = [
                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     ("madm_layernorm_fwd", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
                                    c_void_p]),
+    ("madm_softmax_rows", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     ("madm_attention_fwd", c_int, [ctypes.POINTER(AttentionArgs), c_void_p]),
     ("madm_image_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                    c_float, c_void_p, c_void_p]),

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const IgemmP p, int p
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int n = n0 + lrow + 32 * i;
-        wvoff[i] = (n < p.N) ? (unsigned)(((size_t)n * p.K + cpos * EPC) * sizeof(T)) : OOB;
+        wvoff[i] = (n < p.N) ? (unsigned)(((size_t)n * p.ldw + cpos * EPC) * sizeof(T)) : OOB;
     }
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.bytes1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in2 ? p.in2 : p.in1), 0,

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int n = n0 + lrow + 32 * i;
-        wvoff[i] = (n < p.N) ? (unsigned)(((size_t)n * p.K + chunk * EPC) * sizeof(T)) : OOB;
+        wvoff[i] = (n < p.N) ? (unsigned)(((size_t)n * p.ldw + chunk * EPC) * sizeof(T)) : OOB;
     }
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.bytes1, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in2 ? p.in2 : p.in1), 0,
@@ -357,6 +357,10 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     p.N = a->N; p.K = a->KH * a->KW * p.Ctot; p.M = a->B * a->OH * a->OW;
     MADM_REQUIRE(!a->rowvec || (a->ldrv >= a->N && a->ldrv % 4 == 0), "conv2d: bad ldrv=%d", a->ldrv);
     p.ldr = a->ldr; p.ldo = a->ldo; p.ldrv = a->ldrv; p.epilogue = a->epilogue;
+    p.ldw = a->ldw ? a->ldw : p.K;
+    p.out_f32 = a->out_f32 ? 1 : 0;
+    MADM_REQUIRE(p.ldw >= p.K && p.ldw % (bke / 8) == 0, "conv2d: bad weight row stride ldw=%d", p.ldw);
+    MADM_REQUIRE(!p.out_f32 || (a->epilogue == MADM_EPI_NONE && !a->residual), "conv2d: out_f32 needs the plain epilogue");
     p.ld1 = a->ld1 ? a->ld1 : a->C1;
     p.ld2 = a->ld2 ? a->ld2 : a->C2;
     MADM_REQUIRE(p.ld1 >= a->C1 && p.ld2 >= a->C2 && p.ld1 % (bke / 8) == 0 && p.ld2 % (bke / 8) == 0,
@@ -366,7 +370,7 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
         const size_t px = (size_t)a->B * a->IH * a->IW;
         const size_t b1 = ((px - 1) * p.ld1 + a->C1) * es;
         const size_t b2 = a->C2 ? ((px - 1) * p.ld2 + a->C2) * es : 0;
-        const size_t bw = (size_t)a->N * p.K * es;
+        const size_t bw = ((size_t)(a->N - 1) * p.ldw + p.K) * es;
         MADM_REQUIRE(b1 < 0x80000000ull && b2 < 0x80000000ull && bw < 0x80000000ull,
                      "conv2d: tensors must stay below 2 GiB (32-bit buffer offsets)");
         p.bytes1 = (unsigned)b1; p.bytes2 = (unsigned)b2; p.bytesw = (unsigned)bw;

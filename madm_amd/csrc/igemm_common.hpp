@@ -9,7 +9,7 @@ struct IgemmP {
     const char* in1; const char* in2; const char* w;
     const float* bias; const float* rowvec; const char* residual; char* out; float* ws; double* stats;
     int C1, C2, Ctot, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
-    int N, K, M, ldr, ldo, ldrv, epilogue, splitk, tilesN, nk, ld1, ld2;
+    int N, K, M, ldr, ldo, ldrv, epilogue, splitk, tilesN, nk, ld1, ld2, ldw, out_f32;
     unsigned bytes1, bytes2, bytesw;
     // halo-tile 3x3 conv only: fused GroupNorm(+SiLU) of the INPUT, y = act(x * gn_scale[b][c] + gn_shift[b][c])
     const float* gn_scale; const float* gn_shift; int act;
@@ -42,7 +42,8 @@ __device__ __forceinline__ f32x4 epilogue_store(const IgemmP& p, int m, int n, f
             f32x4 r = load4<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
             v += r;
         }
-        store4<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+        if (p.out_f32) store4<float>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
+        else store4<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
         return v;
     }
 }

@@ -224,9 +224,69 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// ---- row softmax: p = softmax(scale * s) over the last dim of f32 [rows][L] -> dtype [rows][ldp] --------
+// one wave per row, the row held in registers (L <= 64 * 4 * MAXV); used by the GEMM-based VAE mid-block
+// attention (single head, d = 512, L = 4096) where the logits are materialised once in f32.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ sIn, T* __restrict__ pOut,
+                                                           int rows, int L, int lds_, int ldp, float scale_log2) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = sIn + (size_t)row * lds_;
+    float4 v[MAXV];
+    float mx = -INFINITY;
+    const int nq = L / 4;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq) {
+            v[i] = *reinterpret_cast<const float4*>(sr + q * 4);
+            mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float mb = mx * scale_log2;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq) {
+            v[i].x = __builtin_amdgcn_exp2f(v[i].x * scale_log2 - mb);
+            v[i].y = __builtin_amdgcn_exp2f(v[i].y * scale_log2 - mb);
+            v[i].z = __builtin_amdgcn_exp2f(v[i].z * scale_log2 - mb);
+            v[i].w = __builtin_amdgcn_exp2f(v[i].w * scale_log2 - mb);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    T* pr = pOut + (size_t)row * ldp;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int q = lane + 64 * i;
+        if (q < nq) store4<T>(pr + q * 4, f32x4{v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv});
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int madm_softmax_rows(int dtype, const float* s, void* p, int rows, int L, int lds, int ldp, float scale,
+                      void* stream) {
+    MADM_REQUIRE(s && p && rows > 0 && L > 0 && L % 4 == 0 && lds >= L && ldp >= L && lds % 4 == 0 && ldp % 4 == 0,
+                 "softmax_rows: bad args");
+    MADM_REQUIRE(L <= 64 * 4 * 16, "softmax_rows: L=%d too long (max 4096)", L);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    const float sl2 = scale * 1.44269504088896340736f;
+    MADM_DISPATCH_DTYPE(dtype, (softmax_rows_kernel<T, 16><<<grid, 256, 0, st>>>(s, (T*)p, rows, L, lds, ldp, sl2)));
+    return madm_check_launch("softmax_rows_kernel");
+}
+
 
 int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, double* chsums, void* stream) {
     MADM_REQUIRE(x && chsums, "groupnorm_stats: null pointer");

@@ -100,7 +100,7 @@ def _workspace(nbytes, device):
 
 def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
            upsample=False, bias=None, rowvec=None, residual=None, epilogue=EPI_NONE, out=None,
-           splitk=None, alg_nk=None, stats=None, gn=None):
+           splitk=None, alg_nk=None, stats=None, gn=None, out_f32=False):
     """Implicit-GEMM conv / linear.  x1: [B*IH*IW, C1] dense; x2 optional second source (concat);
     w: packed [N, KH*KW*(C1+C2)]; returns out [B*OH*OW, N] (N/2 columns for GEGLU)."""
     _need_cuda(x1, w, x2, bias, rowvec, residual, out)
@@ -108,16 +108,17 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     C2 = 0 if x2 is None else x2.shape[1]
     assert x1.stride(1) == 1 and x1.shape[0] == B * IH * IW, (x1.shape, B, IH, IW)
     assert x2 is None or (x2.stride(1) == 1 and x2.shape[0] == x1.shape[0] and x2.dtype == x1.dtype)
-    assert w.dtype == x1.dtype and w.is_contiguous() and tuple(w.shape) == (N, KH * KW * (C1 + C2)), \
+    assert w.dtype == x1.dtype and w.stride(1) == 1 and tuple(w.shape) == (N, KH * KW * (C1 + C2)), \
         (w.shape, N, KH, KW, C1, C2)
     if OH is None:
         OH = IH * (2 if upsample else 1)
         OW = IW * (2 if upsample else 1)
     M = B * OH * OW
     ocols = N // 2 if epilogue == EPI_GEGLU else N
+    odt = torch.float32 if out_f32 else x1.dtype
     if out is None:
-        out = torch.empty((M, ocols), dtype=x1.dtype, device=x1.device)
-    assert out.shape == (M, ocols) and out.stride(1) == 1 and out.dtype == x1.dtype
+        out = torch.empty((M, ocols), dtype=odt, device=x1.device)
+    assert out.shape == (M, ocols) and out.stride(1) == 1 and out.dtype == odt
     a = Conv2dArgs()
     a.dtype = dtype_code(x1)
     a.in1 = x1.data_ptr()
@@ -129,6 +130,8 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     a.KH, a.KW, a.stride, a.pad_t, a.pad_l = KH, KW, stride, pad_t, pad_l
     a.upsample = 1 if upsample else 0
     a.w = w.data_ptr()
+    a.ldw = w.stride(0)
+    a.out_f32 = 1 if out_f32 else 0
     a.N = N
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N
@@ -179,13 +182,24 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
 
 
 def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=None, splitk=None, alg_nk=None,
-           stats=None, B=1):
+           stats=None, B=1, out_f32=False):
     """out = x @ w.T (+bias) (+residual); x: [M, K] dense, w: [N, K(+K2)].  ``stats`` ([B, N, 2]) asks for
     the fused GroupNorm statistics of the output, the M rows being B images of M/B tokens."""
     M = x.shape[0]
     assert M % B == 0
     return conv2d(x, w, B, M // B, 1, N=w.shape[0], x2=x2, bias=bias, residual=residual,
-                  epilogue=epilogue, out=out, splitk=splitk, alg_nk=alg_nk, stats=stats)
+                  epilogue=epilogue, out=out, splitk=splitk, alg_nk=alg_nk, stats=stats, out_f32=out_f32)
+
+
+def softmax_rows(s, dtype, scale):
+    """softmax(scale * s) over the last dim of the f32 logits [rows, L] -> [rows, L] of ``dtype``."""
+    _need_cuda(s)
+    assert s.dtype == torch.float32 and s.stride(1) == 1
+    rows, L = s.shape
+    out = torch.empty((rows, L), dtype=dtype, device=s.device)
+    check(lib.madm_softmax_rows(dtype_code(dtype), s.data_ptr(), out.data_ptr(), rows, L, s.stride(0), out.stride(0),
+                                float(scale), _stream()), "madm_softmax_rows")
+    return out
 
 
 class StatsArena:

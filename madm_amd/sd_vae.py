@@ -25,18 +25,44 @@ class VaeAttention(nn.Module):
         self.to_v = Linear(channels, channels)
         self.to_out = nn.ModuleList([Linear(channels, channels), Identity()])
 
+    GEMM_MIN_L = 1024   # from this sequence length on, GEMM tiles beat the flash kernel at d = 512
+
+    def _fused(self, key, layers):
+        f = self.__dict__.get(key)
+        if f is None or any(a is not b for a, b in zip(f._layers, layers)):
+            f = _FusedProj(layers)
+            self.__dict__[key] = f
+        return f
+
     def forward(self, x):
-        C = self.channels
-        f_qkv = self.__dict__.get("_f_qkv")
-        if f_qkv is None or f_qkv._layers[0] is not self.to_q:
-            f_qkv = _FusedProj([self.to_q, self.to_k, self.to_v])
-            self.__dict__["_f_qkv"] = f_qkv
+        C, B, L = self.channels, x.B, x.HW
         h = self.group_norm(x)
-        qkv = f_qkv(h.t)
-        o = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, 1, x.HW, x.HW, C, C ** -0.5)
-        st = ops.new_chsums(x.B, C, x.t.device)
-        out = self.to_out[0](o, residual=x.t, stats=st, B=x.B)
-        return Tok(out, x.B, x.H, x.W, st)
+        dtype = h.t.dtype
+        if L >= self.GEMM_MIN_L and L % ops.k_tile(dtype) == 0:
+            o = self._attend_gemm(h.t, B, L)
+        else:
+            qkv = self._fused("_f_qkv", [self.to_q, self.to_k, self.to_v])(h.t)
+            o = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, 1, L, L, C, C ** -0.5)
+        st = ops.new_chsums(B, C, x.t.device)
+        out = self.to_out[0](o, residual=x.t, stats=st, B=B)
+        return Tok(out, B, x.H, x.W, st)
+
+    def _attend_gemm(self, h, B, L):
+        """softmax(Q K^T / sqrt(C)) V as three GEMMs per image on the conv/linear kernel:
+        S = Q K^T (f32 logits), P = softmax rows, O = P V.  V^T is produced directly by a GEMM with the operands
+        swapped (V^T = W_v h^T); its bias is added after P V, exact because the rows of P sum to 1."""
+        C = self.channels
+        dtype = h.dtype
+        qk = self._fused("_f_qk", [self.to_q, self.to_k])(h)          # [B*L, 2C] incl. biases
+        wv, bv = self.to_v.packed(dtype)                                 # [C, C], f32 [C]
+        o = torch.empty((B * L, C), dtype=dtype, device=h.device)
+        for b in range(B):
+            rows = slice(b * L, (b + 1) * L)
+            vT = ops.linear(wv, h[rows])                                 # [C, L] = W_v h_b^T
+            s = ops.linear(qk[rows, :C], qk[rows, C:], out_f32=True)     # [L, L] f32 logits
+            p = ops.softmax_rows(s, dtype, C ** -0.5)
+            ops.linear(p, vT, bias=bv, out=o[rows])
+        return o
 
 
 class UNetMidBlock2D(nn.Module):

@@ -276,6 +276,37 @@ def test_attention(cuda, dtype, case):
     assert e < (2e-5 if dtype == torch.float32 else 1.5e-2), f"{e:.3e} {l2:.3e}"
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_vae_attention_gemm_path_equals_flash_path(cuda, dtype):
+    """The VAE mid-block attention as GEMMs (S = QK^T in f32, row softmax, P V with V^T from a swapped GEMM,
+    bias after P V) against torch SDPA, and the row-softmax kernel on its own."""
+    from madm_amd import ops, weights
+    from madm_amd.sd_vae import VaeAttention
+    from madm_amd.nn import Tok
+    C, B, H, W = 512, 2, 16, 16
+    att = weights.synth_init_(VaeAttention(C), 3, "a.").cuda()
+    x = _q(_gen((B, C, H, W), 1), dtype)
+    att.GEMM_MIN_L = 64
+    got = att(Tok(to_tokens(x, dtype), B, H, W))
+    att.GEMM_MIN_L = 1 << 30
+    flash = att(Tok(to_tokens(x, dtype), B, H, W))
+    with torch.no_grad():
+        sd = {k: v.float().cpu() for k, v in att.state_dict().items()}
+        hn = F.group_norm(x, 32, sd["group_norm.weight"], sd["group_norm.bias"], eps=1e-6)
+        t = hn.reshape(B, C, H * W).transpose(1, 2)
+        q = F.linear(t, sd["to_q.weight"], sd["to_q.bias"])
+        k = F.linear(t, sd["to_k.weight"], sd["to_k.bias"])
+        v = F.linear(t, sd["to_v.weight"], sd["to_v.bias"])
+        o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+        ref = F.linear(o, sd["to_out.0.weight"], sd["to_out.0.bias"]).transpose(1, 2).reshape(B, C, H, W) + x
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(from_tokens(got.t, B, H, W), ref)[0] < tol
+    assert rel_err(from_tokens(flash.t, B, H, W), ref)[0] < tol
+    s = _gen((37, 256), 9) * 5
+    p = ops.softmax_rows(s.cuda(), dtype, 0.3).float().cpu()
+    assert rel_err(p, torch.softmax(s * 0.3, -1))[0] < (1e-6 if dtype == torch.float32 else 5e-3)
+
+
 def test_attention_spike(cuda):
     """Forces the online-softmax rescale: one key dominates late in the sequence."""
     from madm_amd import ops
