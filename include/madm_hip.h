@@ -219,6 +219,13 @@ int madm_silu(int dtype, const void* x, void* y, size_t n, void* stream);
  * (ldm_diffusers.py:505-509) and the dtype->f32 hand-over of time rows to madm_conv2d_fwd. */
 int madm_rows_to_f32(int dtype, const void* x, const float* add, float* y, size_t n, void* stream);
 
+/* dst[r][0..C) = src[r][0..C) between row-strided tensors of dtype (widening the 4-channel UNet sample to
+ * the K-tile-wide input of the VAE decoder's post_quant_conv, ldm_diffusers.py:319-320). */
+int madm_copy_columns(int dtype, const void* src, int lds, void* dst, int ldd, size_t rows, int C,
+                      void* stream);
+/* y = clamp(x, lo, hi) on f32: torch.clip(decoder_output, -1, 1) of 'after_vae.decoder' (ldm_diffusers.py:214). */
+int madm_clamp_f32(const float* x, float* y, size_t n, float lo, float hi, void* stream);
+
 /* y (dtype) = x (f32), n elements: hand-over of f32 conditioning rows (cond_emb, prompt
  * embeddings; ldm_base.py:877-887) to the compute dtype. */
 int madm_cast_from_f32(int dtype, const float* x, void* y, size_t n, void* stream);

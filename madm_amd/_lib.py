@@ -91,6 +91,8 @@ SYMBOLS = [
     ("madm_timestep_embedding", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     ("madm_silu", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("madm_rows_to_f32", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("madm_copy_columns", c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_size_t, c_int, c_void_p]),
+    ("madm_clamp_f32", c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p]),
     ("madm_cast_from_f32", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("madm_nhwc_to_nchw_f32", c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p]),

@@ -162,6 +162,24 @@ __global__ void cast_from_f32_kernel(const float* __restrict__ x, T* __restrict_
         TT<T>::st(y + i, x[i]);
 }
 
+// dst[r][0..C) = src[r][0..C) for two row-strided 2-D tensors of the same dtype (tiny channel counts:
+// widening the 4-channel latent to a K-tile-wide buffer)
+template <typename T>
+__global__ void copy_columns_kernel(const T* __restrict__ src, int lds_, T* __restrict__ dst, int ldd, size_t rows,
+                                    int C) {
+    const size_t total = rows * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / C;
+        const int c = (int)(i - r * C);
+        dst[r * ldd + c] = src[r * lds_ + c];
+    }
+}
+
+__global__ void clamp_f32_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float lo, float hi) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
 // [B*HW][ld] (first C channels) -> channels [c_off, c_off + C) of [B][Ctot][HW] f32, 32x32 LDS tile transpose
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ x, int ld, float* __restrict__ out,
@@ -262,6 +280,20 @@ int madm_rows_to_f32(int dtype, const void* x, const float* add, float* y, size_
     hipStream_t s = (hipStream_t)stream;
     MADM_DISPATCH_DTYPE(dtype, (rows_to_f32_kernel<T><<<grid_for(n), 256, 0, s>>>((const T*)x, add, y, n)));
     return madm_check_launch("rows_to_f32_kernel");
+}
+
+int madm_copy_columns(int dtype, const void* src, int lds, void* dst, int ldd, size_t rows, int C, void* stream) {
+    MADM_REQUIRE(src && dst && rows > 0 && C > 0 && lds >= C && ldd >= C, "copy_columns: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (copy_columns_kernel<T><<<grid_for(rows * C), 256, 0, s>>>((const T*)src, lds, (T*)dst,
+                                                                                         ldd, rows, C)));
+    return madm_check_launch("copy_columns_kernel");
+}
+
+int madm_clamp_f32(const float* x, float* y, size_t n, float lo, float hi, void* stream) {
+    MADM_REQUIRE(x && y && n > 0 && lo <= hi, "clamp_f32: bad args");
+    clamp_f32_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(x, y, n, lo, hi);
+    return madm_check_launch("clamp_f32_kernel");
 }
 
 int madm_cast_from_f32(int dtype, const float* x, void* y, size_t n, void* stream) {

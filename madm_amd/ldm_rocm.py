@@ -64,6 +64,19 @@ def vae_encoder(vae, images, encoder_block_indices):
     return lat, [t.nchw() for t in taps]
 
 
+@torch.no_grad()
+def vae_decoder(vae, latents, decoder_block_indices, output_final=False):
+    """Reference signature (ldm_diffusers.py:314-346): NCHW latents [B,4,h,w] (scaled by scaling_factor, as
+    vae_encoder returns them) -> (image [B,3,8h,8w] f32 or None, list of tap tensors NCHW, taken BEFORE
+    the indexed up-block resnet)."""
+    dtype = _compute_dtype(vae)
+    ops.ARENA.reset(latents.device)
+    B, C, h, w = latents.shape
+    z = Tok(ops.nchw_to_nhwc(latents.float().contiguous(), dtype, ops.k_tile(dtype)), B, h, w)
+    sample, taps = vae.decode(z, tuple(decoder_block_indices), output_final)
+    return (None if sample is None else sample.nchw(3)), [t.nchw() for t in taps]
+
+
 _const_cache = {}
 
 
@@ -232,9 +245,6 @@ class LdmRocm(nn.Module):
         self.register_buffer("_minmax_init", torch.tensor([float("inf"), float("-inf")]), persistent=False)
         self.vae_decoder_loss = vae_decoder_loss
         self.final_fuse_vae_decoder_feat = final_fuse_vae_decoder_feat
-        if vae_decoder_loss or len(decoder_block_indices) != 0:
-            raise NotImplementedError("LdmRocm: the VAE-decoder branch (ldm_diffusers.py:192-207) is the next row "
-                                      "of the scope table (SURVEY.md 8f rank 1)")
         self.to(device)
         self._freeze()
 
@@ -322,16 +332,37 @@ class LdmRocm(nn.Module):
 
         encoder_features = [t.nchw() for t in enc_taps]
         unet_features = [_tap_nchw(t) for t in unet_taps]
-        decoder_features = []
+        # VAE-decoder branch (:192-207)
+        decoder_output = None
+        if self.vae_decoder_loss:
+            dec, _ = self.vae.decode(sample, (), output_final=True)
+            decoder_output = dec.nchw(3)          # no autograd on this path: already "detached"
+            if self.final_fuse_vae_decoder_feat:
+                decoder_features = [decoder_output]
+            else:
+                assert len(self.encoder_block_indices) == 0
+                encoder_features = [decoder_output]
+                decoder_features = []
+        else:
+            if len(self.decoder_block_indices) != 0:
+                # taps of the decoder run on the (scaled) latents, not on the UNet output (:204-205)
+                lat_tok = Tok(ops.nchw_to_nhwc(latents, dtype, ops.k_tile(dtype)), B, h, w)
+                _, dtaps = self.vae.decode(lat_tok, tuple(self.decoder_block_indices), output_final=False)
+                decoder_features = [t.nchw() for t in dtaps]
+            else:
+                decoder_features = []
         if minmax is not None and self.check_input_range and not torch.cuda.is_current_stream_capturing():
             lo, hi = minmax.tolist()  # the reference's range assert (:147); one sync per call, like there
             assert -1 <= lo and hi <= 1
+        self.last_sample = sample
         if "return_unet_feats" in batched_inputs.keys() and batched_inputs["return_unet_feats"]:
             return [*encoder_features, *unet_features, *decoder_features], unet_features
         elif "return_unet_final_output" in kwargs.keys() and kwargs["return_unet_final_output"]:
-            raise NotImplementedError("return_unet_final_output needs the VAE-decoder branch (SURVEY.md 8f rank 1)")
+            return [*encoder_features, *unet_features, *decoder_features], {
+                'before_vae.decoder': sample.nchw(self.unet.out_channels),
+                'after_vae.decoder': ops.clamp_f32(decoder_output, -1.0, 1.0),   # needs vae_decoder_loss, as in :214
+            }
         else:
-            self.last_sample = sample
             return [*encoder_features, *unet_features, *decoder_features]
 
 

@@ -354,6 +354,24 @@ def nhwc_to_nchw(xs, B, C, H, W):
     return out
 
 
+def copy_columns(src, dst, C):
+    """dst[:, :C] = src[:, :C] for 2-D row-strided tensors of the same dtype."""
+    _need_cuda(src, dst)
+    assert src.dtype == dst.dtype and src.stride(1) == 1 and dst.stride(1) == 1 and src.shape[0] == dst.shape[0]
+    check(lib.madm_copy_columns(dtype_code(src), src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0),
+                                src.shape[0], C, _stream()), "madm_copy_columns")
+    return dst
+
+
+def clamp_f32(x, lo, hi):
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty_like(x)
+    check(lib.madm_clamp_f32(x.data_ptr(), out.data_ptr(), x.numel(), float(lo), float(hi), _stream()),
+          "madm_clamp_f32")
+    return out
+
+
 def cast_from_f32(x, dtype):
     _need_cuda(x)
     assert x.dtype == torch.float32 and x.is_contiguous()

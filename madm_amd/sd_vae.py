@@ -205,31 +205,33 @@ class AutoencoderKL(_Packed):
 
     # ---- decoder: vae_decoder (ldm_diffusers.py:314-346) ----
     def decode(self, z, decoder_block_indices=(), output_final=True):
-        """z: Tok of UNSCALED latents (channels padded to the K-tile; the 1/scaling_factor of :319 and the
-        1x1 post_quant_conv are folded into decoder.conv_in).  Returns (sample Tok [.., 4 (3 used)] or None, taps)."""
+        """z: Tok of latents [B*h*w, >=4] (first 4 channels used; e.g. the UNet's ``sample``).  Returns
+        (sample Tok [.., 4] whose first 3 channels are the image, or None; taps list[Tok]).
+        ``1/scaling_factor`` (:319) is folded into post_quant_conv's weights; the 4-channel tensors travel in
+        zeroed K-tile-wide buffers so the 1x1 / 3x3 convs read them without a repacking pass."""
         dec = self.decoder
         dtype = z.t.dtype
+        kt = ops.k_tile(dtype)
+        M = z.t.shape[0]
 
         def build():
-            W = dec.conv_in.weight.detach().double()                   # [512, 4, 3, 3]
-            Wp_ = self.post_quant_conv.weight.detach().double()[:, :, 0, 0]  # [4, 4]
-            bp_ = self.post_quant_conv.bias.detach().double()
-            s = 1.0 / self.config.scaling_factor
-            # conv_in(post_quant(z * s)) = sum_c W[o,c] (sum_i Wp[c,i] s z_i + bp[c]); the bp term is NOT a
-            # constant bias under zero padding, so post_quant's bias is kept exact by an extra input channel
-            # that carries 1 inside the image (channel index 4 of the padded latent tensor).
-            Wf = torch.einsum("ockl,ci->oikl", W, Wp_) * s
-            Wb = torch.einsum("ockl,c->okl", W, bp_)[:, None]
-            Wf = torch.cat([Wf, Wb], dim=1).float()                    # [512, 5, 3, 3]
-            return packing.pack_conv_weight(Wf, dtype, ops.k_tile(dtype)), dec.conv_in.bias.detach().float().contiguous()
+            Wp_ = self.post_quant_conv.weight.detach().float() * (1.0 / self.config.scaling_factor)
+            return (packing.pack_conv_weight(Wp_, dtype, kt), self.post_quant_conv.bias.detach().float().contiguous())
 
-        wp, bp = self._cache_get((dtype, "dec_in"), build)
-        h = ops.conv2d(z.t, wp, z.B, z.H, z.W, N=wp.shape[0], KH=3, KW=3, pad_t=1, pad_l=1, bias=bp)
-        h = dec.mid_block(z.like(h))
+        wp, bp = self._cache_get((dtype, "post_quant"), build)
+        zin = z.t
+        if zin.shape[1] != kt:   # widen the 4-channel latent to one K-tile (zeros above channel 3)
+            buf = torch.zeros((M, kt), dtype=dtype, device=zin.device)
+            ops.copy_columns(zin, buf, 4)
+            zin = buf
+        pq = torch.zeros((M, kt), dtype=dtype, device=zin.device)
+        ops.conv2d(zin, wp, z.B, z.H, z.W, N=4, bias=bp, out=pq[:, :4])
+        h = dec.conv_in(Tok(pq, z.B, z.H, z.W))
+        h = dec.mid_block(h)
         taps, index = [], 0
         for blk in dec.up_blocks:
             for resnet in blk.resnets:
-                if index in decoder_block_indices:
+                if index in decoder_block_indices:   # 0-based, BEFORE the resnet (:330-333)
                     taps.append(h)
                 index += 1
                 h = resnet(h)
@@ -238,5 +240,4 @@ class AutoencoderKL(_Packed):
                     h = u(h)
         if not output_final:
             return None, taps
-        h = dec.conv_norm_out(h, silu=True)
-        return dec.conv_out(h), taps
+        return dec.conv_out(h, norm=dec.conv_norm_out, stats=False), taps

@@ -45,7 +45,8 @@ def run_reference(ref, vae, unet, sched, case):
         out, feats = ref.diffusion_unet(unet=unet, sample=noisy, timestep=timesteps, encoder_hidden_states=cond_inputs,
                                         res_time_embedding=cond_emb.clone(), unet_block_indices=[5, 8, 11],
                                         unet_block_indices_type='after')
-    return latents, noisy, out.sample, feats
+        dec, _ = ref.vae_decoder(vae=vae, latents=out.sample, decoder_block_indices=[], output_final=True)  # :194
+    return latents, noisy, out.sample, feats, dec
 
 
 def main():
@@ -63,9 +64,12 @@ def main():
             models[key] = build_oracle(lora=key)
         vae, unet = models[key]
         t0 = time.time()
-        latents, noisy, sample, feats = run_reference(ref, vae, unet, sched, case)
+        latents, noisy, sample, feats, dec = run_reference(ref, vae, unet, sched, case)
         stride = CH_STRIDE_FULL if name.startswith("full") else 1
-        out = {"latents": latents.numpy(), "noisy": noisy.numpy(), "sample": sample.numpy()}
+        dstride = 4 if name.startswith("full") else 1   # the 512x512 decoder image is stored 4x subsampled
+        out = {"latents": latents.numpy(), "noisy": noisy.numpy(), "sample": sample.numpy(),
+               "decoder": dec[:, :, ::dstride, ::dstride].contiguous().numpy(),
+               "decoder_shape": np.array(dec.shape, dtype=np.int64)}
         for i, f in enumerate(feats):
             out[f"tap{i}"] = f[:, ::stride].contiguous().numpy()
             out[f"tap{i}_stats"] = np.array([f.mean().item(), f.std().item(), f.abs().max().item()], dtype=np.float64)

@@ -83,6 +83,42 @@ def test_golden_lora(cuda, dtype):
     _compare("small_t60", _run(m, CASES["small_t60"], dtype), base, dtype)
 
 
+@pytest.mark.parametrize("name", ["small_t60", "full_t0"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_golden_vae_decoder_branch(extractor, name, dtype):
+    """vae_decoder_loss branch of LdmDiffusers.forward (:192-201, all three shipped task configs): the
+    decoded UNet sample replaces the encoder feature slot, and return_unet_final_output hands back
+    {'before_vae.decoder', 'after_vae.decoder' (clipped)} (:211-215)."""
+    m = extractor
+    case = CASES[name]
+    gold = load_golden(name)
+    images, cond_inputs, cond_emb, timesteps, _ = make_inputs(**case)
+    m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = dtype
+    m.vae_decoder_loss = True
+    try:
+        t = case["t"]
+        feats, extra = m({"img": images.cuda(), "cond_inputs": cond_inputs.cuda(), "cond_emb": cond_emb.cuda(),
+                          "timestep": (t, t + 1)}, "rgb", return_unet_final_output=True)
+        torch.cuda.synchronize()
+    finally:
+        m.vae_decoder_loss = False
+    assert len(feats) == 4 and tuple(feats[0].shape) == tuple(gold["decoder_shape"].tolist())
+    ds = 4 if name.startswith("full") else 1
+    dec = feats[0].cpu()[:, :, ::ds, ::ds]
+    e, l2 = rel_err(dec, gold["decoder"])
+    e2, l22 = rel_err(extra["before_vae.decoder"].cpu(), gold["sample"])
+    print(name, dtype, f"decoder max {e:.2e} l2 {l2:.2e}; sample max {e2:.2e}")
+    if dtype == torch.float32:
+        assert e < F32_TOL and e2 < F32_TOL
+    else:
+        assert l2 < 6e-2 and l22 < BF16_L2_TOL    # ~110 layers end to end in bf16
+    clipped = extra["after_vae.decoder"].cpu()
+    assert clipped.min() >= -1 and clipped.max() <= 1
+    assert torch.equal(clipped, feats[0].cpu().clamp(-1, 1))
+    for i, f in enumerate(feats[1:]):
+        assert rel_err(tap_subset(name, f.cpu()), gold[f"tap{i}"])[1] < (1e-4 if dtype == torch.float32 else BF16_L2_TOL)
+
+
 def test_batch_invariance_and_determinism(extractor):
     """Size-independent properties at the full 512x512 size in bf16: images are independent units
     (GroupNorm/LayerNorm are per-sample), so a batch of two equal images gives two equal outputs that
@@ -136,3 +172,10 @@ def test_helper_functions_match_reference_signatures(extractor):
                                        encoder_hidden_states=cond_inputs.cuda(), res_time_embedding=None,
                                        unet_block_indices=[0, 5, 11], unet_block_indices_type='in')
     assert [t.shape[1] for t in itaps] == [2560, 1920, 640]
+    # vae_decoder: reference signature (:314), taps are taken BEFORE the indexed resnet (:330-333)
+    dec, dtaps = ldm_rocm.vae_decoder(vae=m.vae, latents=torch.from_numpy(gold["sample"].numpy()).cuda(),
+                                      decoder_block_indices=[0, 3], output_final=True)
+    assert rel_err(dec.cpu(), gold["decoder"])[0] < F32_TOL
+    assert [tuple(t.shape[1:]) for t in dtaps] == [(512, 8, 8), (512, 16, 16)]
+    none, _ = ldm_rocm.vae_decoder(vae=m.vae, latents=latents, decoder_block_indices=[], output_final=False)
+    assert none is None
