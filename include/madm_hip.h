@@ -42,12 +42,18 @@ typedef enum {
 
 typedef enum { MADM_F32 = 0, MADM_BF16 = 1 } madm_dtype;
 
+/* activation codes of the norm / conv-input fusions */
+typedef enum { MADM_ACT_NONE = 0, MADM_ACT_SILU = 1, MADM_ACT_RELU = 2 } madm_act;
+
 typedef enum {
     MADM_EPI_NONE = 0,
     /* weight rows interleaved (value_j, gate_j); out[m][j] = value * gelu_erf(gate); the
      * output has N/2 columns.  diffusers GEGLU inside BasicTransformerBlock.ff, reached
      * from ldm_diffusers.py:436-440,528-534,553-559 */
-    MADM_EPI_GEGLU = 1
+    MADM_EPI_GEGLU = 1,
+    /* out = relu(acc + bias + ... + residual): mmcv ConvModule(conv -> BatchNorm (folded into w / bias in
+     * eval mode) -> ReLU) of the DAFormer head (modeling/sem_seg_head/daformer_head.py:364-372,455-461) */
+    MADM_EPI_RELU = 2
 } madm_epilogue;
 
 int madm_abi_version(void);
@@ -100,7 +106,8 @@ typedef struct {
      * madm_conv2d_can_fuse_groupnorm): the conv reads RAW sources and applies
      * y = act(x * gn_scale[b][c] + gn_shift[b][c]) while staging its LDS halo tile, zero padding after the
      * activation; gn_scale / gn_shift are f32 [B][C1+C2] from madm_groupnorm_finalize, NULL = off;
-     * gn_act: 0 = affine only, 1 = SiLU (ResnetBlock2D norm1/norm2 + nonlinearity, conv_norm_out + conv_act) */
+     * gn_act: madm_act (SiLU: ResnetBlock2D norm1/norm2 + nonlinearity, conv_norm_out + conv_act; ReLU: d2
+     * BottleneckBlock conv1.norm + relu before its 3x3 conv2) */
     const float* gn_scale;
     const float* gn_shift;
     int gn_act;
@@ -130,10 +137,12 @@ void madm_debug_set_conv_tile(int tile);
  * arrays `chsums` [B][C][2], one per source: produced either by the epilogue of the conv that wrote
  * the source (madm_conv2d_args.stats) or by madm_groupnorm_stats.
  *   stats: adds x's channel sums into the caller-zeroed chsums[B][C][2].
- *   apply: y[.., c_off + c] = (x - mean_g) * rstd_g * gamma[c_off + c] + beta[c_off + c] (+ SiLU) for the
- *          dense source x [B*HW][C] occupying channels [c_off, c_off + C) of the concatenation; group
+ *   apply: y[.., c_off + c] = act((x - mean_g) * rstd_g * gamma[c_off + c] + beta[c_off + c] + residual) for
+ *          the dense source x [B*HW][C] occupying channels [c_off, c_off + C) of the concatenation; group
  *          statistics come from sums1 (channels [0, C1)) and sums2 (channels [C1, Ctot), may be NULL
- *          when C1 == Ctot); y has row stride ldy.
+ *          when C1 == Ctot); y has row stride ldy; act is a madm_act; residual (may be NULL, row stride
+ *          ldres, same channel window) is added before the activation: detectron2 BottleneckBlock's
+ *          relu(norm(conv3) + shortcut) (modeling/backbone/feature_extractor.py:347-359).
  * Replaces diffusers ResnetBlock2D.norm1/norm2 + nonlinearity, Transformer2DModel.norm,
  * Attention.group_norm (VAE), conv_norm_out + conv_act
  * (ldm_diffusers.py:290,297,299-300,387,435,553,609-610).
@@ -141,7 +150,8 @@ void madm_debug_set_conv_tile(int tile);
 int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, double* chsums, void* stream);
 int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int HW, int C,
                          int c_off, int Ctot, int G, const double* sums1, int C1, const double* sums2,
-                         const float* gamma, const float* beta, float eps, int silu, void* stream);
+                         const float* gamma, const float* beta, float eps, int act,
+                         const void* residual, int ldres, void* stream);
 
 /* channel sums -> the per-(image, channel) affine of the GroupNorm, scale/shift f32 [B][Ctot]:
  * y = x * scale + shift == (x - mean_g) * rstd_g * gamma + beta; input of madm_conv2d_args.gn_scale/gn_shift. */
@@ -238,6 +248,35 @@ int madm_nhwc_to_nchw_f32(int dtype, const void* x, int ld, float* out, int B, i
 /* NCHW f32 [B,C,H,W] -> channels-last dtype [B*HW][Cpad] (zero padded). */
 int madm_nchw_f32_to_nhwc(int dtype, const float* x, void* out, int B, int C, int HW, int Cpad,
                           void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Projection / segmentation-head rows.
+ * ------------------------------------------------------------------------------- */
+/* F.interpolate(mode='bilinear', align_corners=False) on channels-last tokens: in [B*IH*IW][ldi] (C channels)
+ * -> out [B*OH*OW][ldo]; `out` may point into a wider concatenation buffer (DAFormerHead.forward resize + cat,
+ * modeling/sem_seg_head/daformer_head.py:729-746; MTMADISE eval upsampling, mtmadise.py:687-691). */
+int madm_resize_bilinear(int dtype, const void* in, int ldi, void* out, int ldo, int B, int IH, int IW,
+                         int OH, int OW, int C, void* stream);
+/* the same on `planes` NCHW f32 planes (backbone preprocess_image T.Resize, feature_extractor.py:77-79,140-146). */
+int madm_resize_bilinear_nchw_f32(const float* in, float* out, int planes, int IH, int IW, int OH, int OW,
+                                  void* stream);
+/* out[pl][y][x] = (y < IH && x < IW) ? in[pl][y][x] * scale : 0 on `planes` f32 planes: "/255" + the zero padding
+ * of ImageList.from_tensors (OH >= IH; mtmadise.py:668-670) or the final crop to the original size (OH <= IH; :688). */
+int madm_scale_pad_crop_nchw_f32(const float* in, float* out, int planes, int IH, int IW, int OH, int OW,
+                                 float scale, void* stream);
+/* depthwise 3x3 conv (dilation d, padding d, stride 1) on channels-last x [B*H*W][C] with w [9][C] f32
+ * (tap-major), then y = act(acc * scale[c] + shift[c]) (scale/shift = eval-mode BatchNorm folded):
+ * mmcv DepthwiseSeparableConvModule.depthwise_conv of the sep-ASPP (daformer_head.py:383-398). */
+int madm_dwconv3x3(int dtype, const void* x, const float* w, const float* scale, const float* shift, void* y,
+                   int ldy, int B, int H, int W, int C, int dilation, int act, void* stream);
+/* out[r][i] = tanh(a1[i]) x1[i] + tanh(a2[i]) x2[i] for r < repeat (a1/a2 NULL = gate 1, x2 NULL = one term):
+ * ClipFeatureProject.get_cond_prompt / get_cond_time + the batch repeat_interleave
+ * (modeling/meta_arch/ldm_base.py:675-712,915-917). */
+int madm_tanh_gate(const float* a1, const float* x1, const float* a2, const float* x2, float* out, size_t n,
+                   int repeat, void* stream);
+/* labels[b][p] = argmax_k logits[b][k][p] (first maximal k, torch.argmax semantics; bit-exact index op):
+ * evaluation/d2_evaluator.py:106. */
+int madm_argmax_nchw_f32(const float* x, int64_t* out, int B, int K, size_t HW, void* stream);
 
 #ifdef __cplusplus
 }

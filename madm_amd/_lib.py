@@ -14,6 +14,8 @@ MADM_F32 = 0
 MADM_BF16 = 1
 EPI_NONE = 0
 EPI_GEGLU = 1
+EPI_RELU = 2
+ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -77,7 +79,8 @@ SYMBOLS = [
     ("madm_debug_set_conv_tile", None, [c_int]),
     ("madm_groupnorm_stats", c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("madm_groupnorm_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
+                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int,
+                                     c_void_p]),
     ("madm_layernorm_fwd", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
                                    c_void_p]),
     ("madm_softmax_rows", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
@@ -96,6 +99,14 @@ SYMBOLS = [
     ("madm_cast_from_f32", c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("madm_nhwc_to_nchw_f32", c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p]),
+    ("madm_resize_bilinear", c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     c_void_p]),
+    ("madm_resize_bilinear_nchw_f32", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    ("madm_scale_pad_crop_nchw_f32", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    ("madm_dwconv3x3", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_void_p]),
+    ("madm_tanh_gate", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    ("madm_argmax_nchw_f32", c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_void_p]),
     ("madm_nchw_f32_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 ]
 

@@ -109,6 +109,10 @@ __device__ __forceinline__ void mma16<float>(const uint4& a, const uint4& b, f32
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// madm_act: 0 = none, 1 = SiLU, 2 = ReLU
+__device__ __forceinline__ float act_f(float x, int act) {
+    return act == 1 ? silu_f(x) : (act == 2 ? fmaxf(x, 0.f) : x);
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

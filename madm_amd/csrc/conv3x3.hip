@@ -24,7 +24,7 @@ __device__ __forceinline__ u32x4 gn_act_chunk(u32x4 raw, const float* sc, const 
 #pragma unroll
     for (int j = 0; j < EPC; ++j) {
         const float t = f[j] * sc[j] + sh[j];
-        f[j] = act ? silu_f(t) : t;
+        f[j] = act_f(t, act);
     }
     return __builtin_bit_cast(u32x4, f32_to_chunk<T>(f));
 }

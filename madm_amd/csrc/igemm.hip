@@ -301,7 +301,7 @@ int heuristic_tile(int M, int N) {
 // the LDS halo-tile kernel (conv3x3.hip) handles 3x3 / stride 1 / pad 1 convs on maps of at least one patch
 bool halo_eligible(const madm_conv2d_args* a) {
     return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && !a->upsample &&
-           a->OH == a->IH && a->OW == a->IW && a->OH >= 8 && a->OW >= 16 && a->epilogue == MADM_EPI_NONE;
+           a->OH == a->IH && a->OW == a->IW && a->OH >= 8 && a->OW >= 16 && a->epilogue != MADM_EPI_GEGLU;
 }
 
 // tile codes: 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 BN=128, 5 = halo BN=64
@@ -339,7 +339,7 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     MADM_REQUIRE(a->B > 0 && a->IH > 0 && a->IW > 0 && a->OH > 0 && a->OW > 0, "conv2d: bad dims");
     MADM_REQUIRE(a->KH > 0 && a->KW > 0 && a->stride > 0, "conv2d: bad kernel/stride");
     MADM_REQUIRE(a->N > 0 && a->N % 4 == 0, "conv2d: N=%d must be a positive multiple of 4", a->N);
-    MADM_REQUIRE(a->epilogue == MADM_EPI_NONE || a->epilogue == MADM_EPI_GEGLU, "conv2d: bad epilogue");
+    MADM_REQUIRE(a->epilogue >= MADM_EPI_NONE && a->epilogue <= MADM_EPI_RELU, "conv2d: bad epilogue");
     MADM_REQUIRE(a->splitk >= 1, "conv2d: splitk must be >= 1");
     const int ocols = (a->epilogue == MADM_EPI_GEGLU) ? a->N / 2 : a->N;
     MADM_REQUIRE(a->ldo >= ocols && a->ldo % 2 == 0, "conv2d: ldo=%d too small/odd for %d columns", a->ldo, ocols);
@@ -349,7 +349,7 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     p.bias = a->bias; p.rowvec = a->rowvec; p.residual = (const char*)a->residual;
     p.out = (char*)a->out; p.ws = (float*)a->workspace; p.stats = a->stats;
     p.gn_scale = nullptr; p.gn_shift = nullptr; p.act = 0;
-    MADM_REQUIRE(!a->stats || a->epilogue == MADM_EPI_NONE, "conv2d: fused statistics need the plain epilogue");
+    MADM_REQUIRE(!a->stats || a->epilogue != MADM_EPI_GEGLU, "conv2d: fused statistics cannot follow GEGLU");
     p.C1 = a->C1; p.C2 = a->C2; p.Ctot = a->C1 + a->C2;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW;
     p.KH = a->KH; p.KW = a->KW; p.stride = a->stride; p.pad_t = a->pad_t; p.pad_l = a->pad_l;
@@ -360,7 +360,7 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     p.ldw = a->ldw ? a->ldw : p.K;
     p.out_f32 = a->out_f32 ? 1 : 0;
     MADM_REQUIRE(p.ldw >= p.K && p.ldw % (bke / 8) == 0, "conv2d: bad weight row stride ldw=%d", p.ldw);
-    MADM_REQUIRE(!p.out_f32 || (a->epilogue == MADM_EPI_NONE && !a->residual), "conv2d: out_f32 needs the plain epilogue");
+    MADM_REQUIRE(!p.out_f32 || (a->epilogue != MADM_EPI_GEGLU && !a->residual), "conv2d: out_f32 cannot follow GEGLU / residual");
     p.ld1 = a->ld1 ? a->ld1 : a->C1;
     p.ld2 = a->ld2 ? a->ld2 : a->C2;
     MADM_REQUIRE(p.ld1 >= a->C1 && p.ld2 >= a->C2 && p.ld1 % (bke / 8) == 0 && p.ld2 % (bke / 8) == 0,

@@ -42,6 +42,9 @@ __device__ __forceinline__ f32x4 epilogue_store(const IgemmP& p, int m, int n, f
             f32x4 r = load4<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
             v += r;
         }
+        if (p.epilogue == MADM_EPI_RELU) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
         if (p.out_f32) store4<float>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
         else store4<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
         return v;

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                        const double* __restrict__ sums1, int C1,
                                                        const double* __restrict__ sums2,
                                                        const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, float eps, int silu) {
+                                                       const float* __restrict__ beta, float eps, int act,
+                                                       const T* __restrict__ res, int ldres) {
     constexpr int EPC = TT<T>::EPC;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // scale[C], shift[C], gmean[G], grstd[G]
     float* scale = lds;
@@ -114,12 +115,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         const unsigned r = idx / CPR;
         const unsigned q = idx - r * CPR;
         uint4 v = *reinterpret_cast<const uint4*>(xb + (size_t)idx * EPC);
-        float f[EPC];
+        float f[EPC], g[EPC];
         chunk_to_f32<T>(v, f);
+        if (res) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(res + ((size_t)b * HW + r) * ldres + c_off + q * EPC);
+            chunk_to_f32<T>(rv, g);
+        }
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
             float t = f[j] * scale[q * EPC + j] + shift[q * EPC + j];
-            f[j] = silu ? silu_f(t) : t;
+            if (res) t += g[j];
+            f[j] = act_f(t, act);
         }
         *reinterpret_cast<uint4*>(yb + (size_t)r * ldy + q * EPC) = f32_to_chunk<T>(f);
     }
@@ -310,13 +316,14 @@ int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, double*
 
 int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int HW, int C, int c_off, int Ctot,
                          int G, const double* sums1, int C1, const double* sums2, const float* gamma,
-                         const float* beta, float eps, int silu, void* stream) {
+                         const float* beta, float eps, int act, const void* residual, int ldres, void* stream) {
     MADM_REQUIRE(x && y && sums1 && gamma && beta, "groupnorm_apply: null pointer");
     MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && Ctot % G == 0 && c_off >= 0 && c_off + C <= Ctot && ldy >= c_off + C,
                  "groupnorm_apply: bad dims");
     MADM_REQUIRE(C1 > 0 && C1 <= Ctot && (C1 == Ctot || sums2), "groupnorm_apply: bad statistics sources (C1=%d Ctot=%d)", C1, Ctot);
     const int epc = dtype == MADM_BF16 ? 8 : 4;
     MADM_REQUIRE(C % epc == 0 && c_off % epc == 0 && ldy % epc == 0, "groupnorm_apply: C/c_off/ldy must be multiples of %d", epc);
+    MADM_REQUIRE(act >= 0 && act <= 2 && (!residual || (ldres >= c_off + C && ldres % epc == 0)), "groupnorm_apply: bad act/residual");
     const size_t shm = ((size_t)2 * C + 2 * G) * sizeof(float);
     MADM_REQUIRE(shm <= 64 * 1024, "groupnorm_apply: C=%d too large", C);
     const size_t total = (size_t)HW * (C / epc);
@@ -328,7 +335,8 @@ int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int 
     dim3 grid((unsigned)strips, (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
     MADM_DISPATCH_DTYPE(dtype, (gn_apply_kernel<T><<<grid, 256, shm, s>>>((const T*)x, (T*)y, ldy, HW, C, c_off, Ctot, G,
-                                                                        sums1, C1, sums2, gamma, beta, eps, silu)));
+                                                                        sums1, C1, sums2, gamma, beta, eps, act,
+                                                                        (const T*)residual, ldres)));
     return madm_check_launch("gn_apply_kernel");
 }
 

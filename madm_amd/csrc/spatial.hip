@@ -1,0 +1,215 @@
+// Spatial glue of the projection / segmentation-head rows of the path:
+// bilinear resize (tokens and NCHW images), depthwise dilated 3x3 conv (+ folded BatchNorm + ReLU),
+// tanh-gated prompt / time conditioning, per-pixel argmax.  All HBM-bound streaming kernels.
+#include "common.hpp"
+
+namespace {
+
+// PyTorch F.interpolate(mode='bilinear', align_corners=False) source index / weight
+__device__ __forceinline__ void bilinear_coord(int o, int in_size, float scale, int& i0, int& i1, float& l1) {
+    float src = ((float)o + 0.5f) * scale - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+// channels-last: in [B*IH*IW][ldi] (C channels) -> out [B*OH*OW][ldo] (out already points at its column offset)
+template <typename T>
+__global__ __launch_bounds__(256) void resize_bilinear_tokens_kernel(const T* __restrict__ in, int ldi, T* __restrict__ out,
+                                                                     int ldo, int B, int IH, int IW, int OH, int OW,
+                                                                     int C) {
+    constexpr int EPC = TT<T>::EPC;
+    const unsigned CPR = (unsigned)C / EPC;
+    const unsigned total = (unsigned)B * OH * OW * CPR;
+    const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned q = idx % CPR;
+        const unsigned pix = idx / CPR;
+        const unsigned ox = pix % (unsigned)OW;
+        const unsigned t = pix / (unsigned)OW;
+        const unsigned oy = t % (unsigned)OH;
+        const unsigned b = t / (unsigned)OH;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilinear_coord((int)oy, IH, sy, y0, y1, ly);
+        bilinear_coord((int)ox, IW, sx, x0, x1, lx);
+        const T* base = in + (size_t)b * IH * IW * ldi + q * EPC;
+        float a[EPC], c[EPC], d[EPC], e[EPC], o[EPC];
+        chunk_to_f32<T>(*reinterpret_cast<const uint4*>(base + ((size_t)y0 * IW + x0) * ldi), a);
+        chunk_to_f32<T>(*reinterpret_cast<const uint4*>(base + ((size_t)y0 * IW + x1) * ldi), c);
+        chunk_to_f32<T>(*reinterpret_cast<const uint4*>(base + ((size_t)y1 * IW + x0) * ldi), d);
+        chunk_to_f32<T>(*reinterpret_cast<const uint4*>(base + ((size_t)y1 * IW + x1) * ldi), e);
+        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) o[j] = w00 * a[j] + w01 * c[j] + w10 * d[j] + w11 * e[j];
+        *reinterpret_cast<uint4*>(out + (size_t)pix * ldo + q * EPC) = f32_to_chunk<T>(o);
+    }
+}
+
+// NCHW f32 planes
+__global__ __launch_bounds__(256) void resize_bilinear_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                   int planes, int IH, int IW, int OH, int OW) {
+    const size_t total = (size_t)planes * OH * OW;
+    const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % OW);
+        const size_t t = idx / OW;
+        const int oy = (int)(t % OH);
+        const size_t pl = t / OH;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilinear_coord(oy, IH, sy, y0, y1, ly);
+        bilinear_coord(ox, IW, sx, x0, x1, lx);
+        const float* p = in + pl * IH * IW;
+        const float top = p[(size_t)y0 * IW + x0] * (1.f - lx) + p[(size_t)y0 * IW + x1] * lx;
+        const float bot = p[(size_t)y1 * IW + x0] * (1.f - lx) + p[(size_t)y1 * IW + x1] * lx;
+        out[idx] = top * (1.f - ly) + bot * ly;
+    }
+}
+
+// depthwise 3x3, dilation d, padding d, stride 1; w [9][C] f32 (tap-major), then y = act(acc * scale[c] + shift[c])
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        T* __restrict__ y, int ldy, int B, int H, int W, int C, int dil,
+                                                        int act) {
+    constexpr int EPC = TT<T>::EPC;
+    const unsigned CPR = (unsigned)C / EPC;
+    const unsigned total = (unsigned)B * H * W * CPR;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned q = idx % CPR;
+        const unsigned pix = idx / CPR;
+        const int ox = (int)(pix % (unsigned)W);
+        const unsigned t = pix / (unsigned)W;
+        const int oy = (int)(t % (unsigned)H);
+        const unsigned b = t / (unsigned)H;
+        float acc[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy + (r - 1) * dil;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ix = ox + (s - 1) * dil;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                float f[EPC];
+                chunk_to_f32<T>(*reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + q * EPC), f);
+                const float* wt = w + (size_t)(r * 3 + s) * C + q * EPC;
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) acc[j] += f[j] * wt[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) acc[j] = act_f(acc[j] * scale[q * EPC + j] + shift[q * EPC + j], act);
+        *reinterpret_cast<uint4*>(y + (size_t)pix * ldy + q * EPC) = f32_to_chunk<T>(acc);
+    }
+}
+
+// out[pl][y][x] = (y < IH && x < IW) ? in[pl][y][x] * scale : 0  -- zero padding (OH >= IH) or cropping (OH <= IH)
+__global__ void scale_pad_crop_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int IH, int IW,
+                                      int OH, int OW, float scale) {
+    const size_t total = (size_t)planes * OH * OW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % OW);
+        const size_t t = idx / OW;
+        const int y = (int)(t % OH);
+        const size_t pl = t / OH;
+        out[idx] = (y < IH && x < IW) ? in[(pl * IH + y) * IW + x] * scale : 0.f;
+    }
+}
+
+__global__ void tanh_gate_kernel(const float* __restrict__ a1, const float* __restrict__ x1, const float* __restrict__ a2,
+                                 const float* __restrict__ x2, float* __restrict__ out, size_t n, int repeat) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = (a1 ? tanhf(a1[i]) : 1.f) * x1[i];
+        if (x2) v += (a2 ? tanhf(a2[i]) : 1.f) * x2[i];
+        for (int r = 0; r < repeat; ++r) out[(size_t)r * n + i] = v;
+    }
+}
+
+// NCHW f32 logits [B][K][HW] -> int64 labels [B][HW]; first maximal channel wins (torch.argmax semantics)
+__global__ void argmax_nchw_kernel(const float* __restrict__ x, int64_t* __restrict__ out, int B, int K, size_t HW) {
+    const size_t total = (size_t)B * HW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = idx / HW, p = idx - b * HW;
+        const float* px = x + b * K * HW + p;
+        float best = px[0];
+        int bi = 0;
+        for (int k = 1; k < K; ++k) {
+            const float v = px[(size_t)k * HW];
+            if (v > best || (v != v && best == best)) { best = v; bi = k; }   // NaN counts as maximal, like torch
+        }
+        out[idx] = bi;
+    }
+}
+
+unsigned grid_for(size_t n, unsigned cap = 4096) {
+    size_t g = (n + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int madm_resize_bilinear(int dtype, const void* in, int ldi, void* out, int ldo, int B, int IH, int IW, int OH, int OW,
+                         int C, void* stream) {
+    MADM_REQUIRE(in && out && B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0, "resize_bilinear: bad args");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(C % epc == 0 && ldi >= C && ldo >= C && ldi % epc == 0 && ldo % epc == 0, "resize_bilinear: C/ld must be multiples of %d", epc);
+    const size_t total = (size_t)B * OH * OW * (C / epc);
+    MADM_REQUIRE(total < 0x7fffffffull, "resize_bilinear: tensor too large for 32-bit indexing");
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (resize_bilinear_tokens_kernel<T><<<grid_for(total), 256, 0, s>>>(
+                                   (const T*)in, ldi, (T*)out, ldo, B, IH, IW, OH, OW, C)));
+    return madm_check_launch("resize_bilinear_tokens_kernel");
+}
+
+int madm_resize_bilinear_nchw_f32(const float* in, float* out, int planes, int IH, int IW, int OH, int OW, void* stream) {
+    MADM_REQUIRE(in && out && planes > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "resize_bilinear_nchw: bad args");
+    resize_bilinear_nchw_kernel<<<grid_for((size_t)planes * OH * OW), 256, 0, (hipStream_t)stream>>>(in, out, planes, IH,
+                                                                                                   IW, OH, OW);
+    return madm_check_launch("resize_bilinear_nchw_kernel");
+}
+
+int madm_dwconv3x3(int dtype, const void* x, const float* w, const float* scale, const float* shift, void* y, int ldy,
+                   int B, int H, int W, int C, int dilation, int act, void* stream) {
+    MADM_REQUIRE(x && w && scale && shift && y && B > 0 && H > 0 && W > 0 && C > 0 && dilation > 0, "dwconv3x3: bad args");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(C % epc == 0 && ldy >= C && ldy % epc == 0 && act >= 0 && act <= 2, "dwconv3x3: bad C/ldy/act");
+    const size_t total = (size_t)B * H * W * (C / epc);
+    MADM_REQUIRE(total < 0x7fffffffull, "dwconv3x3: tensor too large for 32-bit indexing");
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (dwconv3x3_kernel<T><<<grid_for(total, 16384), 256, 0, s>>>((const T*)x, w, scale, shift, (T*)y,
+                                                                                        ldy, B, H, W, C, dilation, act)));
+    return madm_check_launch("dwconv3x3_kernel");
+}
+
+int madm_scale_pad_crop_nchw_f32(const float* in, float* out, int planes, int IH, int IW, int OH, int OW, float scale,
+                                 void* stream) {
+    MADM_REQUIRE(in && out && planes > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "scale_pad_crop: bad args");
+    scale_pad_crop_kernel<<<grid_for((size_t)planes * OH * OW), 256, 0, (hipStream_t)stream>>>(in, out, planes, IH, IW, OH,
+                                                                                             OW, scale);
+    return madm_check_launch("scale_pad_crop_kernel");
+}
+
+int madm_tanh_gate(const float* a1, const float* x1, const float* a2, const float* x2, float* out, size_t n, int repeat,
+                   void* stream) {
+    MADM_REQUIRE(x1 && out && n > 0 && repeat > 0 && (!a2 || x2), "tanh_gate: bad args");
+    tanh_gate_kernel<<<grid_for(n), 256, 0, (hipStream_t)stream>>>(a1, x1, a2, x2, out, n, repeat);
+    return madm_check_launch("tanh_gate_kernel");
+}
+
+int madm_argmax_nchw_f32(const float* x, int64_t* out, int B, int K, size_t HW, void* stream) {
+    MADM_REQUIRE(x && out && B > 0 && K > 0 && HW > 0, "argmax_nchw: bad args");
+    argmax_nchw_kernel<<<grid_for((size_t)B * HW), 256, 0, (hipStream_t)stream>>>(x, out, B, K, HW);
+    return madm_check_launch("argmax_nchw_kernel");
+}
+
+}  // extern "C"

@@ -330,40 +330,48 @@ class LdmRocm(nn.Module):
         sample, unet_taps = _unet_tokens(forward_unet, Tok(noisy, B, h, w), timesteps, text_prompt,
                                          res_time_embedding, self.unet_block_indices, self.unet_block_indices_type)
 
-        encoder_features = [t.nchw() for t in enc_taps]
-        unet_features = [_tap_nchw(t) for t in unet_taps]
-        # VAE-decoder branch (:192-207)
+        # feature lists as channels-last Toks; converted to NCHW f32 at the API boundary unless the (HIP) backbone
+        # asked for tokens (madm_amd.backbone passes _return_tokens=True)
+        as_tok = bool(kwargs.get("_return_tokens", False))
+        enc_tok, unet_tok, dec_tok = list(enc_taps), list(unet_taps), []
         decoder_output = None
-        if self.vae_decoder_loss:
+        if self.vae_decoder_loss:   # :192-201
             dec, _ = self.vae.decode(sample, (), output_final=True)
-            decoder_output = dec.nchw(3)          # no autograd on this path: already "detached"
+            decoder_output = dec        # Tok [.., 4], image in the first 3 channels; no autograd here: "detached"
             if self.final_fuse_vae_decoder_feat:
-                decoder_features = [decoder_output]
+                dec_tok = [dec]
             else:
                 assert len(self.encoder_block_indices) == 0
-                encoder_features = [decoder_output]
-                decoder_features = []
-        else:
-            if len(self.decoder_block_indices) != 0:
-                # taps of the decoder run on the (scaled) latents, not on the UNet output (:204-205)
-                lat_tok = Tok(ops.nchw_to_nhwc(latents, dtype, ops.k_tile(dtype)), B, h, w)
-                _, dtaps = self.vae.decode(lat_tok, tuple(self.decoder_block_indices), output_final=False)
-                decoder_features = [t.nchw() for t in dtaps]
-            else:
-                decoder_features = []
+                enc_tok = [dec]
+        elif len(self.decoder_block_indices) != 0:
+            # taps of the decoder run on the (scaled) latents, not on the UNet output (:204-205)
+            lat_tok = Tok(ops.nchw_to_nhwc(latents, dtype, ops.k_tile(dtype)), B, h, w)
+            _, dec_tok = self.vae.decode(lat_tok, tuple(self.decoder_block_indices), output_final=False)
         if minmax is not None and self.check_input_range and not torch.cuda.is_current_stream_capturing():
             lo, hi = minmax.tolist()  # the reference's range assert (:147); one sync per call, like there
             assert -1 <= lo and hi <= 1
         self.last_sample = sample
+
+        def out(t):
+            if as_tok:
+                if isinstance(t, tuple):
+                    raise NotImplementedError("'in'-type taps are handed over as NCHW tensors only")
+                return t
+            if t is decoder_output:
+                return t.nchw(3)
+            return _tap_nchw(t)
+
+        feats = [out(t) for t in (*enc_tok, *unet_tok, *dec_tok)]
         if "return_unet_feats" in batched_inputs.keys() and batched_inputs["return_unet_feats"]:
-            return [*encoder_features, *unet_features, *decoder_features], unet_features
+            return feats, [out(t) for t in unet_tok]
         elif "return_unet_final_output" in kwargs.keys() and kwargs["return_unet_final_output"]:
-            return [*encoder_features, *unet_features, *decoder_features], {
+            return feats, {
                 'before_vae.decoder': sample.nchw(self.unet.out_channels),
-                'after_vae.decoder': ops.clamp_f32(decoder_output, -1.0, 1.0),   # needs vae_decoder_loss, as in :214
+                # like the reference (:214) this needs the vae_decoder_loss branch
+                'after_vae.decoder': ops.clamp_f32(decoder_output.nchw(3), -1.0, 1.0),
             }
         else:
-            return [*encoder_features, *unet_features, *decoder_features]
+            return feats
 
 
 weights_loader = weights

@@ -136,7 +136,7 @@ class Conv2d(_Packed):
                                                       norm.bias.detach(), norm.eps)
                 gn = (scale, shift, act)
             else:
-                x = norm(x, silu=act, x2=x2)
+                x = norm(x, act=act, x2=x2)
                 x2 = None
         splits = None
         if x2 is not None:
@@ -183,12 +183,13 @@ class GroupNorm(nn.Module):
         self.weight = nn.Parameter(torch.empty(num_channels))
         self.bias = nn.Parameter(torch.empty(num_channels))
 
-    def forward(self, x, silu=False, x2=None):
-        """GroupNorm(+SiLU) of x, or of the channel concatenation [x | x2]; returns one dense Tok."""
+    def forward(self, x, silu=False, x2=None, act=None, residual=None):
+        """act(GroupNorm([x | x2]) + residual); ``act``: None/'silu'/'relu' (``silu=True`` is the short form);
+        returns one dense Tok."""
         xs = [x.t] if x2 is None else [x.t, x2.t]
         st = [x.stats] if x2 is None else [x.stats, x2.stats]
         t = ops.groupnorm(xs, x.B, x.HW, self.num_groups, self.weight.detach(), self.bias.detach(), self.eps,
-                          silu=silu, stats=st)
+                          silu=silu, stats=st, act=act, residual=None if residual is None else residual.t)
         return x.like(t)
 
 

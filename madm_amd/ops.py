@@ -9,7 +9,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import lib, check, Conv2dArgs, AttentionArgs, EPI_NONE, EPI_GEGLU, MADM_F32, MADM_BF16
+from ._lib import (lib, check, Conv2dArgs, AttentionArgs, EPI_NONE, EPI_GEGLU, EPI_RELU, MADM_F32, MADM_BF16,
+                   ACT_NONE, ACT_SILU, ACT_RELU)
 
 _DT = {torch.float32: MADM_F32, torch.bfloat16: MADM_BF16}
 
@@ -154,7 +155,7 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         gs, gh, act = gn
         assert gs.dtype == torch.float32 and gh.dtype == torch.float32 and gs.is_contiguous() and gh.is_contiguous()
         assert gs.numel() == B * (C1 + C2) and gh.numel() == gs.numel()
-        a.gn_scale, a.gn_shift, a.gn_act = gs.data_ptr(), gh.data_ptr(), 1 if act else 0
+        a.gn_scale, a.gn_shift, a.gn_act = gs.data_ptr(), gh.data_ptr(), _act_code(act=act)
     a.splitk = 1
     if splitk is None:
         splitk = lib.madm_conv2d_suggest_splitk(ctypes.byref(a))
@@ -246,7 +247,17 @@ def groupnorm_stats(x, B, HW, chsums):
           "madm_groupnorm_stats")
 
 
-def groupnorm(xs, B, HW, G, gamma, beta, eps, silu=False, stats=None):
+def _act_code(silu=False, act=None):
+    if act is None:
+        return ACT_SILU if silu else ACT_NONE
+    if isinstance(act, str):
+        return {"none": ACT_NONE, "silu": ACT_SILU, "relu": ACT_RELU}[act]
+    if isinstance(act, bool):
+        return ACT_SILU if act else ACT_NONE
+    return int(act)
+
+
+def groupnorm(xs, B, HW, G, gamma, beta, eps, silu=False, stats=None, act=None, residual=None):
     """GroupNorm(+SiLU) of the channel concatenation of one or two sources ``xs`` (a tensor or a list
     of [B*HW, C_i] tensors); ``stats`` = matching list of chsums tensors [B, C_i, 2] (from the producing
     conv's epilogue) or None entries (computed here).  Returns the normalised [B*HW, sum C_i] tensor."""
@@ -270,7 +281,9 @@ def groupnorm(xs, B, HW, G, gamma, beta, eps, silu=False, stats=None):
         assert x.is_contiguous()
         check(lib.madm_groupnorm_apply(dtype_code(x), x.data_ptr(), out.data_ptr(), out.stride(0), B, HW, x.shape[1],
                                        off, Ctot, G, stats[0].data_ptr(), C1, s2, gamma.data_ptr(), beta.data_ptr(),
-                                       float(eps), 1 if silu else 0, _stream()), "madm_groupnorm_apply")
+                                       float(eps), _act_code(silu, act), _ptr(residual),
+                                       residual.stride(0) if residual is not None else 0, _stream()),
+              "madm_groupnorm_apply")
         off += x.shape[1]
     return out
 
@@ -428,3 +441,79 @@ def rows_to_f32(x, add=None):
     check(lib.madm_rows_to_f32(dtype_code(x), x.data_ptr(), _ptr(add), out.data_ptr(), x.numel(), _stream()),
           "madm_rows_to_f32")
     return out
+
+
+def resize_bilinear(x, B, IH, IW, OH, OW, out=None):
+    """F.interpolate(bilinear, align_corners=False) on tokens x [B*IH*IW, C] -> [B*OH*OW, C]; ``out`` may be a
+    column window of a wider concatenation buffer."""
+    _need_cuda(x, out)
+    assert x.stride(1) == 1 and x.shape[0] == B * IH * IW
+    C = x.shape[1]
+    if out is None:
+        out = torch.empty((B * OH * OW, C), dtype=x.dtype, device=x.device)
+    assert out.shape == (B * OH * OW, C) and out.stride(1) == 1 and out.dtype == x.dtype
+    check(lib.madm_resize_bilinear(dtype_code(x), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), B, IH, IW, OH, OW,
+                                   C, _stream()), "madm_resize_bilinear")
+    return out
+
+
+def resize_bilinear_nchw(x, OH, OW):
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, C, IH, IW = x.shape
+    out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+    check(lib.madm_resize_bilinear_nchw_f32(x.data_ptr(), out.data_ptr(), B * C, IH, IW, OH, OW, _stream()),
+          "madm_resize_bilinear_nchw_f32")
+    return out
+
+
+def dwconv3x3(x, w9c, scale, shift, B, H, W, dilation, act=ACT_RELU, out=None):
+    """Depthwise dilated 3x3 conv + per-channel affine + activation on tokens x [B*H*W, C]; w9c f32 [9, C]."""
+    _need_cuda(x, w9c, scale, shift, out)
+    C = x.shape[1]
+    assert x.is_contiguous() and x.shape[0] == B * H * W and tuple(w9c.shape) == (9, C) and w9c.dtype == torch.float32
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.stride(1) == 1 and out.shape == x.shape
+    check(lib.madm_dwconv3x3(dtype_code(x), x.data_ptr(), w9c.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                             out.stride(0), B, H, W, C, dilation, act, _stream()), "madm_dwconv3x3")
+    return out
+
+
+def tanh_gate(x1, a1=None, x2=None, a2=None, repeat=1):
+    """repeat x [tanh(a1) * x1 + tanh(a2) * x2] (f32, flattened): returns [repeat, *x1.shape[1:]] when x1 has a
+    leading 1-dim, else [repeat, *x1.shape]."""
+    _need_cuda(x1, a1, x2, a2)
+    for t in (x1, a1, x2, a2):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == x1.numel())
+    tail = tuple(x1.shape[1:]) if x1.dim() > 1 and x1.shape[0] == 1 else tuple(x1.shape)
+    out = torch.empty((repeat,) + tail, dtype=torch.float32, device=x1.device)
+    check(lib.madm_tanh_gate(_ptr(a1), x1.data_ptr(), _ptr(a2), _ptr(x2), out.data_ptr(), x1.numel(), repeat, _stream()),
+          "madm_tanh_gate")
+    return out
+
+
+def argmax_nchw(x):
+    """[B, K, H, W] f32 logits -> int64 [B, H, W], first maximal channel (torch.argmax(dim=1))."""
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, K, H, W = x.shape
+    out = torch.empty((B, H, W), dtype=torch.int64, device=x.device)
+    check(lib.madm_argmax_nchw_f32(x.data_ptr(), out.data_ptr(), B, K, H * W, _stream()), "madm_argmax_nchw_f32")
+    return out
+
+
+def scale_pad_nchw(x, scale, OH, OW):
+    """x * scale, zero-padded (bottom/right) to [B, C, OH, OW] (f32 NCHW)."""
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    B, C, IH, IW = x.shape
+    out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+    check(lib.madm_scale_pad_crop_nchw_f32(x.data_ptr(), out.data_ptr(), B * C, IH, IW, OH, OW, float(scale), _stream()),
+          "madm_scale_pad_crop_nchw_f32")
+    return out
+
+
+def crop_nchw(x, OH, OW):
+    """x[:, :, :OH, :OW] as a dense tensor."""
+    return scale_pad_nchw(x, 1.0, OH, OW)

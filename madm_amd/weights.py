@@ -24,7 +24,12 @@ def synth_init_(module, seed=0, prefix=""):
     for name, p in module.named_parameters():
         full = prefix + name
         g = _gen(seed, full)
-        if p.dim() >= 2:
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf in ("prompt_embed", "time_embed"):          # trunc_normal_(std=0.02) in the reference (ldm_base.py:653,671)
+            v = 0.02 * torch.randn(p.shape, generator=g)
+        elif leaf.startswith("alpha_"):                     # rand / zeros there; non-trivial gates here
+            v = torch.rand(p.shape, generator=g)
+        elif p.dim() >= 2:
             fan_in = p[0].numel()
             v = torch.randn(p.shape, generator=g) / math.sqrt(fan_in)
         elif name.endswith("weight"):   # GroupNorm / LayerNorm scale
@@ -32,6 +37,18 @@ def synth_init_(module, seed=0, prefix=""):
         else:
             v = 0.1 * torch.randn(p.shape, generator=g)
         p.copy_(v.to(p.dtype))
+    return module
+
+
+@torch.no_grad()
+def synth_buffers_(module, seed=0, prefix=""):
+    """Non-trivial BatchNorm running statistics (eval-mode head): mean 0.1 N(0,1), var 0.5 + U(0,1)."""
+    for name, b in module.named_buffers():
+        g = _gen(seed, prefix + name)
+        if name.endswith("running_mean"):
+            b.copy_(0.1 * torch.randn(b.shape, generator=g))
+        elif name.endswith("running_var"):
+            b.copy_(0.5 + torch.rand(b.shape, generator=g))
     return module
 
 

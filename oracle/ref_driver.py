@@ -60,3 +60,78 @@ def load():
             else:
                 sys.modules[k] = old
     return mod
+
+
+def load_modeling():
+    """Loads the reference's OWN ``BasePromptTimeGenerator`` / ``ClipFeatureProject`` (modeling/meta_arch/ldm_base.py),
+    ``AttentionFeatureExtractorBackbone`` (modeling/backbone/feature_extractor.py) and ``DAFormerHead``
+    (modeling/sem_seg_head/daformer_head.py) from /root/reference, on top of the restated third-party classes of
+    oracle/third_party.py and inert stubs for packages those files import but the hot path never calls.
+    Returns a namespace with the three modules."""
+    from . import third_party as tp
+    root = "/root/reference"
+    saved = {}
+
+    def put(name, mod):
+        saved[name] = sys.modules.get(name)
+        sys.modules[name] = mod
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        put(name, m)
+        return m
+
+    def pkg(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        put(name, m)
+        return m
+
+    try:
+        # real reference packages, WITHOUT running their __init__ (which imports the whole training stack)
+        pkg("modeling", root + "/modeling")
+        pkg("modeling.meta_arch", root + "/modeling/meta_arch")
+        pkg("modeling.backbone", root + "/modeling/backbone")
+        pkg("modeling.sem_seg_head", root + "/modeling/sem_seg_head")
+        # third-party packages: restatements (third_party.py) or inert names
+        stub("torchvision")
+        stub("torchvision.transforms", Resize=tp.Resize, InterpolationMode=tp.InterpolationMode)
+        stub("detectron2")
+        stub("detectron2.modeling")
+        stub("detectron2.modeling.backbone", Backbone=tp.Backbone)
+        stub("detectron2.modeling.backbone.resnet", BottleneckBlock=tp.BottleneckBlock, ResNet=tp.ResNet)
+        stub("detectron2.structures", ImageList=tp.ImageList)
+        stub("mmcv")
+        stub("mmcv.cnn", ConvModule=tp.ConvModule, DepthwiseSeparableConvModule=tp.DepthwiseSeparableConvModule)
+        stub("mmcv.runner", BaseModule=tp.BaseModule)
+        oc = stub("omegaconf", OmegaConf=tp.OmegaConf)
+        oc.listconfig = stub("omegaconf.listconfig", ListConfig=tp.ListConfig)
+        stub("timm")
+        stub("timm.models")
+        stub("timm.models.layers", trunc_normal_=tp.trunc_normal_)
+        for name, attrs in (("ldm", {}), ("ldm.models", {}), ("ldm.models.diffusion", {}),
+                            ("ldm.models.diffusion.ddpm", {"LatentDiffusion": object}),
+                            ("ldm.modules", {}), ("ldm.modules.diffusionmodules", {}),
+                            ("ldm.modules.diffusionmodules.openaimodel", {"timestep_embedding": None}),
+                            ("ldm.modules.distributions", {}),
+                            ("ldm.modules.distributions.distributions", {"DiagonalGaussianDistribution": object}),
+                            ("ldm.util", {"instantiate_from_config": None}),
+                            ("checkpoint", {}), ("checkpoint.odise_checkpointer", {"LdmCheckpointer": object}),
+                            ("modeling.meta_arch.clip", {"ClipAdapter": object}),
+                            ("utils", {}), ("utils.file_io", {"PathManager": object})):
+            stub(name, **attrs)
+        import importlib
+        ns = types.SimpleNamespace()
+        ns.ldm_base = importlib.import_module("modeling.meta_arch.ldm_base")
+        ns.feature_extractor = importlib.import_module("modeling.backbone.feature_extractor")
+        ns.daformer_head = importlib.import_module("modeling.sem_seg_head.daformer_head")
+        return ns
+    finally:
+        for k, old in saved.items():
+            if old is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = old
+        for k in [k for k in sys.modules if k.startswith("modeling.") and k not in saved]:
+            sys.modules.pop(k, None)

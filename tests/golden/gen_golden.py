@@ -23,7 +23,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WEIGHT_SEED = 0
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from golden_util import CASES, CH_STRIDE_FULL, make_inputs, add_lora  # noqa: E402  (shared with the tests)
+from golden_util import CASES, CH_STRIDE_FULL, make_inputs, add_lora, EVAL_CASES, eval_image, init_eval_params  # noqa: E402
 
 
 def build_oracle(lora=False, seed=WEIGHT_SEED):
@@ -78,5 +78,36 @@ def main():
         print(f"{name}: {time.time() - t0:.1f}s", {k: v.shape for k, v in out.items() if not k.endswith('_stats')})
 
 
+def main_eval():
+    """Full inference forward through the REFERENCE's BasePromptTimeGenerator / AttentionFeatureExtractorBackbone /
+    DAFormerHead classes (loaded by path) on the oracle modules; eval post-processing per mtmadise.py:657-691."""
+    from oracle import madm_path
+    only = sys.argv[1:]
+    ns = ref_driver.load_modeling()
+    vae, unet = build_oracle(lora=False)
+    torch.set_num_threads(os.cpu_count())
+    for name, case in EVAL_CASES.items():
+        if only and name not in only:
+            continue
+        cfg = madm_path.DEPTH_CFG if case["cfg"] == "DEPTH" else madm_path.S345_CFG
+        backbone, head = madm_path.build_reference_eval_model(ns, vae, unet, cfg)
+        init_eval_params(backbone, head)
+        t0 = time.time()
+        sem_seg, feats = madm_path.eval_forward(backbone, head, eval_image(case["H"], case["W"]))
+        out = {"sem_seg": sem_seg[:, :, ::4, ::4].contiguous().numpy(),
+               "sem_seg_shape": np.array(sem_seg.shape, dtype=np.int64),
+               "labels": sem_seg[0].argmax(dim=0).to(torch.uint8).numpy(),
+               "top2_margin": (lambda t: (t[0] - t[1]))(sem_seg[0].topk(2, dim=0).values).to(torch.float16).numpy()}
+        for k, f in feats['output_features'].items():
+            st = max(1, f.shape[-1] // 32)
+            out["feat_" + k] = f[:, ::8, ::st, ::st].contiguous().numpy()
+            out["feat_" + k + "_shape"] = np.array(f.shape, dtype=np.int64)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(f"{name}: {time.time() - t0:.1f}s", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if not sys.argv[1:] or any(a in CASES for a in sys.argv[1:]):
+        main()
+    if not sys.argv[1:] or any(a in EVAL_CASES for a in sys.argv[1:]):
+        main_eval()

@@ -54,3 +54,27 @@ def add_lora(unet, LoraConfig, seed=WEIGHT_SEED):
 
 def tap_subset(name, t):
     return t[:, ::CH_STRIDE_FULL] if name.startswith("full") else t
+
+
+# ---- full inference forward (config 3): backbone + head + eval post-processing ---------------------------------
+EVAL_CASES = {
+    # non-512 input: /255, pad to 512x640, T.Resize to 512x512, head at 64x64, bilinear up + crop
+    "eval_s345": dict(cfg="S345", H=480, W=640),
+    # the shipped RGB->Depth configuration: VAE decoder -> s0 projection -> head at 512x512
+    "eval_depth": dict(cfg="DEPTH", H=512, W=512),
+}
+
+
+def eval_image(H, W):
+    return 255.0 * torch.rand((3, H, W), generator=torch.Generator().manual_seed(777))
+
+
+def init_eval_params(backbone, head, seed=WEIGHT_SEED):
+    """Seeded parameters / BatchNorm statistics of everything outside unet/vae (name-keyed: identical values for the
+    reference classes, the oracle restatement and the madm_amd modules)."""
+    from madm_amd import weights
+    for prefix, mod in (("backbone.feature_projections.", backbone.feature_projections),
+                        ("backbone.clip_project_rgb.", backbone.feature_extractor.clip_project_rgb),
+                        ("head.", head)):
+        weights.synth_init_(mod, seed, prefix)
+        weights.synth_buffers_(mod, seed, prefix)

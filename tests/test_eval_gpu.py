@@ -1,0 +1,184 @@
+"""Backbone projections, DAFormer head and the full inference forward (BASELINE config 3) on the GPU through the
+C ABI, against (a) torch-CPU ops / the oracle restatements at small sizes and (b) the committed golden vectors that
+the REFERENCE's own BasePromptTimeGenerator / AttentionFeatureExtractorBackbone / DAFormerHead classes produced
+(tests/golden/gen_golden.py::main_eval).  Index ops (argmax labels) are compared bit-exact."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import EVAL_CASES, eval_image, init_eval_params, load_golden
+from util import to_tokens, from_tokens, rel_err, bf16_round
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _q(x, dtype):
+    return bf16_round(x) if dtype == torch.bfloat16 else x
+
+
+def _gen(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_spatial_kernels(cuda, dtype):
+    from madm_amd import ops
+    kt = ops.k_tile(dtype)
+    # bilinear resize on tokens (up and down, into a column window of a wider buffer)
+    x = _q(_gen((2, 64, 5, 7), 1), dtype)
+    for (oh, ow) in ((20, 28), (3, 4), (5, 7), (16, 9)):
+        ref = F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=False)
+        buf = torch.zeros((2 * oh * ow, 192), dtype=dtype, device="cuda")
+        ops.resize_bilinear(to_tokens(x, dtype), 2, 5, 7, oh, ow, out=buf[:, 64:128])
+        got = from_tokens(buf[:, 64:128], 2, oh, ow)
+        assert rel_err(got, ref)[0] < (1e-6 if dtype == torch.float32 else 8e-3)
+        assert buf[:, :64].abs().max().item() == 0 and buf[:, 128:].abs().max().item() == 0
+    img = torch.rand((2, 3, 30, 50), generator=torch.Generator().manual_seed(2))
+    assert rel_err(ops.resize_bilinear_nchw(img.cuda(), 64, 64).cpu(),
+                   F.interpolate(img, size=(64, 64), mode="bilinear", align_corners=False))[0] < 1e-6
+    # scale + zero pad / crop
+    p = ops.scale_pad_nchw(img.cuda(), 1 / 255.0, 64, 64).cpu()
+    assert torch.equal(p[:, :, :30, :50], img * (1 / 255.0)) and p[:, :, 30:].abs().max() == 0 and p[:, :, :, 50:].abs().max() == 0
+    assert torch.equal(ops.crop_nchw(img.cuda(), 11, 13).cpu(), img[:, :, :11, :13])
+    # depthwise dilated 3x3 + folded BN + ReLU
+    C = 64
+    xd = _q(_gen((2, C, 13, 17), 3), dtype)
+    w = _gen((C, 1, 3, 3), 4) / 3
+    s, t = 1 + 0.1 * _gen((C,), 5), 0.1 * _gen((C,), 6)
+    for dil in (1, 6, 12, 18):
+        ref = F.relu(F.conv2d(xd, w, None, padding=dil, dilation=dil, groups=C) * s[None, :, None, None] + t[None, :, None, None])
+        got = ops.dwconv3x3(to_tokens(xd, dtype), w.reshape(C, 9).t().contiguous().cuda(), s.cuda(), t.cuda(), 2, 13, 17, dil)
+        assert rel_err(from_tokens(got, 2, 13, 17), ref)[0] < (1e-6 if dtype == torch.float32 else 8e-3), dil
+    # tanh gates (prompt / time conditioning) with the batch repeat
+    a1, x1, a2, x2 = torch.rand(1, 77, 768), _gen((1, 77, 768), 7), torch.rand(1, 77, 768), _gen((1, 77, 768), 8)
+    g = ops.tanh_gate(x1.cuda(), a1.cuda(), x2.cuda(), a2.cuda(), repeat=3).cpu()
+    assert g.shape == (3, 77, 768) and rel_err(g, (torch.tanh(a1) * x1 + torch.tanh(a2) * x2).repeat(3, 1, 1))[0] < 1e-6
+    # argmax: first maximal channel wins (bit-exact index op)
+    lg = _gen((2, 11, 9, 10), 9)
+    lg[0, 3, 2, 2] = lg[0, 7, 2, 2] = 100.0
+    lab = ops.argmax_nchw(lg.cuda()).cpu()
+    assert torch.equal(lab, lg.argmax(dim=1)) and lab[0, 2, 2].item() == 3
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(320, 512, 16, 16), (3, 128, 16, 32), (512, 512, 8, 16)], ids=["s3", "s0_rgb", "same_width"])
+def test_bottleneck_block(cuda, dtype, case):
+    """detectron2 BottleneckBlock(GN) of the feature projections (feature_extractor.py:347-359)."""
+    from madm_amd import weights
+    from madm_amd.backbone import BottleneckBlock
+    from madm_amd.nn import Tok
+    from oracle import third_party as tp
+    cin, cout, H, W = case
+    blk = weights.synth_init_(BottleneckBlock(cin, cout, bottleneck_channels=128), 5, "p.").cuda()
+    ref_blk = weights.synth_init_(tp.BottleneckBlock(cin, cout, bottleneck_channels=128, norm="GN"), 5, "p.").eval()
+    assert set(blk.state_dict()) == set(ref_blk.state_dict())
+    x = _q(_gen((2, cin, H, W), 1), dtype)
+    with torch.no_grad():
+        ref = ref_blk(x)
+    cpad = cin if cin % 64 == 0 else 4
+    got = blk(Tok(to_tokens(x, dtype, cpad), 2, H, W))
+    e, l2 = rel_err(from_tokens(got.t, 2, H, W), ref)
+    assert e < (3e-5 if dtype == torch.float32 else 3e-2), f"{e:.2e} {l2:.2e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_daformer_head_small(cuda, dtype):
+    """DAFormerHead (MLP embeds -> bilinear -> concat -> sep-ASPP -> 3x3 bottleneck -> 1x1 classes) against the oracle
+    restatement on mmcv-shaped modules, eval mode, 3 scales."""
+    from madm_amd import weights
+    from madm_amd.head import DAFormerHead
+    from madm_amd.backbone import FeatureDict
+    from madm_amd.nn import Tok
+    from oracle import madm_path
+    cfg = dict(madm_path.S345_CFG)
+    head = DAFormerHead(in_channels=cfg["head_in_channels"], in_keys=cfg["out_features"], in_index=[0, 1, 2], channels=256,
+                        num_classes=11, norm_cfg=dict(type='BN'), decoder_params=madm_path.head_decoder_params())
+    ref = madm_path.OracleHead(cfg).eval()
+    for m in (head, ref):
+        weights.synth_init_(m, 2, "head.")
+        weights.synth_buffers_(m, 2, "head.")
+    assert set(head.state_dict()) == set(ref.state_dict())
+    head = head.cuda().eval()
+    feats = {"s3": _q(_gen((2, 512, 16, 32), 1), dtype), "s4": _q(_gen((2, 512, 8, 16), 2), dtype),
+             "s5": _q(_gen((2, 512, 4, 8), 3), dtype)}
+    with torch.no_grad():
+        want = ref({'output_features': feats})
+    fd = FeatureDict()
+    fd.tok = {k: Tok(to_tokens(v, dtype), 2, v.shape[2], v.shape[3]) for k, v in feats.items()}
+    for k in feats:
+        fd[k] = None
+    got = head({'output_features': fd}).cpu()
+    e, l2 = rel_err(got, want)
+    assert got.shape == want.shape and e < (3e-5 if dtype == torch.float32 else 3e-2), f"{e:.2e} {l2:.2e}"
+
+
+def _build_product(cfg_name, dtype):
+    from madm_amd.ldm_rocm import LdmRocm
+    from madm_amd.backbone import BasePromptTimeGenerator, AttentionFeatureExtractorBackbone
+    from madm_amd.head import DAFormerHead
+    from madm_amd.meta_arch import MadmInference
+    from oracle import madm_path
+    cfg = madm_path.DEPTH_CFG if cfg_name == "DEPTH" else madm_path.S345_CFG
+    ldm = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=(),
+                  input_range='-1+1', unet_block_indices_type='after', finetune_unet='no', compute_dtype=dtype,
+                  weights='synthetic', seed=0, vae_decoder_loss=cfg["vae_decoder_loss"])
+    gen = BasePromptTimeGenerator(learnable_cond_prompt=True, learnable_cond_time=True, clip_state='no', num_timesteps=1,
+                                  clip_model_name="ViT-L-14-336", ldm_extractor=ldm, same_cond_params=True)
+    backbone = AttentionFeatureExtractorBackbone(
+        attention_features_res=None, feature_dims=list(cfg["feature_dims"]), projection_dim=list(cfg["projection_dim"]),
+        attention_features_location=None, feature_extractor=gen, num_res_blocks=1, out_features=list(cfg["out_features"]))
+    n = len(cfg["out_features"])
+    head = DAFormerHead(in_channels=list(cfg["head_in_channels"]), in_keys=list(cfg["out_features"]), in_index=list(range(n)),
+                        channels=256, dropout_ratio=0.1, num_classes=cfg["num_classes"], norm_cfg=dict(type='BN'),
+                        align_corners=False, decoder_params=madm_path.head_decoder_params())
+    init_eval_params(backbone, head)
+    model = MadmInference(backbone.cuda(), head.cuda(), target_modality="Depth").eval()
+    return model
+
+
+@pytest.mark.parametrize("name", ["eval_s345", "eval_depth"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_eval_forward_golden(cuda, name, dtype):
+    """MTMADISE eval forward (mtmadise.py:657-691) end to end vs the vectors of the reference's own classes."""
+    from madm_amd.meta_arch import MadmInference
+    case = EVAL_CASES[name]
+    gold = load_golden(name)
+    model = _build_product(case["cfg"], dtype)
+    img = eval_image(case["H"], case["W"])
+    out = model([{"target_second_modality": img}])
+    torch.cuda.synchronize()
+    sem = out[0]["sem_seg"].cpu()
+    assert tuple(sem.shape) == tuple(gold["sem_seg_shape"].tolist())
+    e, l2 = rel_err(sem[:, :, ::4, ::4], gold["sem_seg"])
+    labels = MadmInference.predict_labels(out[0]).cpu()
+    assert torch.equal(labels, sem[0].argmax(dim=0))          # the device argmax is the torch index op, bit for bit
+    gl = gold["labels"].long()
+    margin = gold["top2_margin"].float()
+    scale = gold["sem_seg"].abs().max().item()
+    agree = (labels == gl).float().mean().item()
+    print(name, dtype, f"sem_seg max {e:.2e} l2 {l2:.2e}; label agreement {agree:.5f}")
+    if dtype == torch.float32:
+        assert e < 1e-3
+        decided = margin > 1e-3 * scale                       # pixels whose top-2 logits are not within fp32 noise
+        assert torch.equal(labels[decided], gl[decided]), "labels differ where the reference margin is decisive"
+        assert agree > 0.9999
+    else:
+        assert l2 < 8e-2 and agree > 0.97
+    feats = model.backbone(model_input(model, img), input_modal='others')['output_features']
+    for k in feats:
+        g = gold["feat_" + k]
+        f = feats[k].cpu()
+        assert tuple(f.shape) == tuple(gold["feat_" + k + "_shape"].tolist())
+        st = max(1, f.shape[-1] // 32)
+        ef, lf = rel_err(f[:, ::8, ::st, ::st], g)
+        assert (ef < 1e-3) if dtype == torch.float32 else (lf < 8e-2), (k, ef, lf)
+
+
+def model_input(model, img):
+    from madm_amd import ops
+    H, W = img.shape[1:]
+    Hp, Wp = (H + 63) // 64 * 64, (W + 63) // 64 * 64
+    return ops.scale_pad_nchw(img[None].cuda().contiguous(), 1 / 255.0, Hp, Wp)
