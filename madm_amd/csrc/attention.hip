@@ -18,6 +18,7 @@ struct AttnP {
     int ldq, ldk, ldv, ldo;
     int B, H, Lq, Lk, D;
     float scale_log2;
+    unsigned bytes_k, bytes_v;
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -30,18 +31,29 @@ struct AttnCfg {
     static constexpr int QK_ROWB = NKB * 64 + 16;    // +16 B pad: odd number of 16-B slots
     static constexpr int V_CH = ND * ES;             // chunks per V row: ND*16 elements
     static constexpr int V_ROWB = ND * 16 * ES + 16;
-    static constexpr size_t LDS_BYTES = (size_t)(BQ + BKV) * QK_ROWB + (size_t)BKV * V_ROWB;
+    // small head dims: Q fragments live in registers and K/V tiles are double-buffered in LDS with the next
+    // tile's global loads in flight during the MFMAs; d = 512 keeps the single-buffered synchronous form
+    static constexpr int KV_TILE_B = BKV * QK_ROWB + BKV * V_ROWB;
+    static constexpr int NT = NW * 64;
+    static constexpr int KI0 = (BKV * QK_CH + NT - 1) / NT;   // K chunks staged per thread (upper bound)
+    static constexpr int VI0 = (BKV * V_CH + NT - 1) / NT;    // V chunks staged per thread (upper bound)
+    static constexpr bool PIPE = (BQ * QK_ROWB + 2 * KV_TILE_B) <= 112 * 1024 && (KI0 + VI0) <= 12 && NKB <= 6;
+    static constexpr int NBUF = PIPE ? 2 : 1;
+    static constexpr size_t LDS_BYTES = (size_t)BQ * QK_ROWB + (size_t)NBUF * KV_TILE_B;
+    static constexpr int KI = PIPE ? KI0 : 1, VI = PIPE ? VI0 : 1;
 };
+
+typedef unsigned int u32x4a __attribute__((ext_vector_type(4)));
 
 template <typename T, int NKB, int ND, int NW, int NS>
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
     using C = AttnCfg<T, NKB, ND, NW, NS>;
     constexpr int ES = C::ES;
-    constexpr int NT = NW * 64;
+    constexpr int NT = C::NT;
+    constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;
-    char* Ks = Qs + C::BQ * C::QK_ROWB;
-    char* Vs = Ks + C::BKV * C::QK_ROWB;
+    char* KV0 = Qs + C::BQ * C::QK_ROWB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
@@ -63,35 +75,115 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
         }
     }
 
+    // ---- K/V staging state: this thread's chunks of a tile (valid chunks only; the padding chunks of the LDS
+    //      rows are zeroed once and never rewritten) ----
+    const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc((void*)p.k, 0, p.bytes_k, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc((void*)p.v, 0, p.bytes_v, 0x00020000);
+    unsigned kgo[C::KI], vgo[C::VI];   // global byte offsets relative to the tile's first key row (OOB = unused slot)
+    int klo[C::KI], vlo[C::VI];        // LDS byte offsets inside a K / V tile
+    int krow[C::KI], vrow[C::VI];
+#pragma unroll
+    for (int i = 0; i < (C::PIPE ? C::KI : 0); ++i) {
+        const int idx = tid + NT * i;
+        const int r = idx / dch, c = idx - r * dch;
+        const bool ok = idx < C::BKV * dch;
+        krow[i] = ok ? r : (1 << 28);
+        kgo[i] = (unsigned)((size_t)r * p.ldk * ES + c * 16);
+        klo[i] = r * C::QK_ROWB + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < (C::PIPE ? C::VI : 0); ++i) {
+        const int idx = tid + NT * i;
+        const int r = idx / dch, c = idx - r * dch;
+        const bool ok = idx < C::BKV * dch;
+        vrow[i] = ok ? r : (1 << 28);
+        vgo[i] = (unsigned)((size_t)r * p.ldv * ES + c * 16);
+        vlo[i] = r * C::V_ROWB + c * 16;
+    }
+    for (int nb = 0; nb < C::NBUF; ++nb) {   // zero the padding chunks once
+        char* Kb = KV0 + nb * C::KV_TILE_B;
+        char* Vb = Kb + C::BKV * C::QK_ROWB;
+        for (int idx = tid; idx < C::BKV * C::QK_CH; idx += NT) {
+            const int r = idx / C::QK_CH, c = idx - r * C::QK_CH;
+            if (c >= dch) *reinterpret_cast<uint4*>(Kb + r * C::QK_ROWB + c * 16) = make_uint4(0, 0, 0, 0);
+        }
+        for (int idx = tid; idx < C::BKV * C::V_CH; idx += NT) {
+            const int r = idx / C::V_CH, c = idx - r * C::V_CH;
+            if (c >= dch) *reinterpret_cast<uint4*>(Vb + r * C::V_ROWB + c * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    u32x4a kr[C::KI], vr[C::VI];
+#define ATTN_LOAD_KV(k0_)                                                                                  \
+    {                                                                                                      \
+        const int rows_valid_ = p.Lk - (k0_);                                                              \
+        const unsigned kb_ = (unsigned)(((size_t)(b * p.Lk + (k0_)) * p.ldk + (size_t)h * p.D) * ES);      \
+        const unsigned vb_ = (unsigned)(((size_t)(b * p.Lk + (k0_)) * p.ldv + (size_t)h * p.D) * ES);      \
+        _Pragma("unroll") for (int i = 0; i < C::KI; ++i)                                                  \
+            kr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsk, krow[i] < rows_valid_ ? kgo[i] + kb_ : OOB, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < C::VI; ++i)                                                  \
+            vr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsv, vrow[i] < rows_valid_ ? vgo[i] + vb_ : OOB, 0, 0); \
+    }
+#define ATTN_STORE_KV(buf_)                                                                                \
+    {                                                                                                      \
+        char* Kb_ = KV0 + (buf_) * C::KV_TILE_B;                                                           \
+        char* Vb_ = Kb_ + C::BKV * C::QK_ROWB;                                                             \
+        _Pragma("unroll") for (int i = 0; i < C::KI; ++i)                                                  \
+            if (krow[i] < C::BKV) *reinterpret_cast<u32x4a*>(Kb_ + klo[i]) = kr[i];                        \
+        _Pragma("unroll") for (int i = 0; i < C::VI; ++i)                                                  \
+            if (vrow[i] < C::BKV) *reinterpret_cast<u32x4a*>(Vb_ + vlo[i]) = vr[i];                        \
+    }
+
+    // single-buffered form (large head dims): straight global -> LDS copy of the valid chunks
+#define ATTN_STAGE_DIRECT(k0_)                                                                             \
+    {                                                                                                      \
+        const int rows_valid_ = p.Lk - (k0_);                                                              \
+        char* Kb_ = KV0;                                                                                   \
+        char* Vb_ = Kb_ + C::BKV * C::QK_ROWB;                                                             \
+        const char* gk_ = p.k + ((size_t)(b * p.Lk + (k0_)) * p.ldk + (size_t)h * p.D) * ES;               \
+        const char* gv_ = p.v + ((size_t)(b * p.Lk + (k0_)) * p.ldv + (size_t)h * p.D) * ES;               \
+        for (int idx = tid; idx < C::BKV * dch; idx += NT) {                                               \
+            const int r = idx / dch, c = idx - r * dch;                                                    \
+            uint4 kv_ = make_uint4(0, 0, 0, 0), vv_ = make_uint4(0, 0, 0, 0);                              \
+            if (r < rows_valid_) {                                                                         \
+                kv_ = *reinterpret_cast<const uint4*>(gk_ + (size_t)r * p.ldk * ES + c * 16);              \
+                vv_ = *reinterpret_cast<const uint4*>(gv_ + (size_t)r * p.ldv * ES + c * 16);              \
+            }                                                                                              \
+            *reinterpret_cast<uint4*>(Kb_ + r * C::QK_ROWB + c * 16) = kv_;                                \
+            *reinterpret_cast<uint4*>(Vb_ + r * C::V_ROWB + c * 16) = vv_;                                 \
+        }                                                                                                  \
+    }
+
     f32x4 o[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (p.Lk + C::BKV - 1) / C::BKV;
+    if constexpr (C::PIPE) {
+        ATTN_LOAD_KV(0);
+        ATTN_STORE_KV(0);
+    } else {
+        ATTN_STAGE_DIRECT(0);
+    }
+    __syncthreads();   // Q, padding zeros and tile 0 visible
+
+    uint4 qreg[C::PIPE ? NKB : 1];
+    if constexpr (C::PIPE) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+            qreg[kb] = *reinterpret_cast<const uint4*>(Qs + (wave * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
+    }
+
     for (int t = 0; t < ntiles; ++t) {
         const int k0 = t * C::BKV;
-        __syncthreads();  // previous tile fully consumed (also orders the Q stores on t == 0)
-        {
-            const int rows_valid = p.Lk - k0;
-            const char* gk = p.k + ((size_t)(b * p.Lk + k0) * p.ldk + (size_t)h * p.D) * ES;
-            for (int idx = tid; idx < C::BKV * C::QK_CH; idx += NT) {
-                const int r = idx / C::QK_CH, c = idx - r * C::QK_CH;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (r < rows_valid && c < dch)
-                    v = *reinterpret_cast<const uint4*>(gk + (size_t)r * p.ldk * ES + c * 16);
-                *reinterpret_cast<uint4*>(Ks + r * C::QK_ROWB + c * 16) = v;
-            }
-            const char* gv = p.v + ((size_t)(b * p.Lk + k0) * p.ldv + (size_t)h * p.D) * ES;
-            for (int idx = tid; idx < C::BKV * C::V_CH; idx += NT) {
-                const int r = idx / C::V_CH, c = idx - r * C::V_CH;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (r < rows_valid && c < dch)
-                    v = *reinterpret_cast<const uint4*>(gv + (size_t)r * p.ldv * ES + c * 16);
-                *reinterpret_cast<uint4*>(Vs + r * C::V_ROWB + c * 16) = v;
-            }
+        const int cur = C::PIPE ? (t & 1) : 0;
+        const bool more = t + 1 < ntiles;
+        if constexpr (C::PIPE) {
+            if (more) ATTN_LOAD_KV(k0 + C::BKV);   // next tile's loads stay in flight during this tile's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        const char* Ks = KV0 + cur * C::KV_TILE_B;
+        const char* Vs = Ks + C::BKV * C::QK_ROWB;
 
         // ---- S^T = K Q^T for this wave's 16 queries ----
         f32x4 s[NS];
@@ -99,7 +191,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
         for (int st = 0; st < NS; ++st) s[st] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            const uint4 qf = *reinterpret_cast<const uint4*>(Qs + (wave * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
+            uint4 qf;
+            if constexpr (C::PIPE) qf = qreg[kb];
+            else qf = *reinterpret_cast<const uint4*>(Qs + (wave * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
                 const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (st * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
@@ -108,16 +202,27 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
         }
         // ---- online softmax (base-2), one query per lane ----
         float mx = -INFINITY;
+        if (k0 + C::BKV <= p.Lk) {   // full tile: no masking (wave-uniform)
 #pragma unroll
-        for (int st = 0; st < NS; ++st)
+            for (int st = 0; st < NS; ++st)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + st * 16 + fg * 4 + r;
-                float v = s[st][r] * p.scale_log2;
-                v = (key < p.Lk) ? v : -INFINITY;
-                s[st][r] = v;
-                mx = fmaxf(mx, v);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const float v = s[st][r] * p.scale_log2;
+                    s[st][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        } else {
+#pragma unroll
+            for (int st = 0; st < NS; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + st * 16 + fg * 4 + r;
+                    float v = s[st][r] * p.scale_log2;
+                    v = (key < p.Lk) ? v : -INFINITY;
+                    s[st][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
@@ -167,19 +272,32 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
             for (int st = 0; st < NS; ++st) {
                 const float4 pf4 = make_float4(s[st][0], s[st][1], s[st][2], s[st][3]);
                 const uint4 pfu = __builtin_bit_cast(uint4, pf4);
-                const char* vr = Vs + (st * 16 + fg * 4) * C::V_ROWB + fi * 4;
+                const char* vr_ = Vs + (st * 16 + fg * 4) * C::V_ROWB + fi * 4;
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
                     float4 vf4;
-                    vf4.x = *reinterpret_cast<const float*>(vr + 0 * C::V_ROWB + d * 64);
-                    vf4.y = *reinterpret_cast<const float*>(vr + 1 * C::V_ROWB + d * 64);
-                    vf4.z = *reinterpret_cast<const float*>(vr + 2 * C::V_ROWB + d * 64);
-                    vf4.w = *reinterpret_cast<const float*>(vr + 3 * C::V_ROWB + d * 64);
+                    vf4.x = *reinterpret_cast<const float*>(vr_ + 0 * C::V_ROWB + d * 64);
+                    vf4.y = *reinterpret_cast<const float*>(vr_ + 1 * C::V_ROWB + d * 64);
+                    vf4.z = *reinterpret_cast<const float*>(vr_ + 2 * C::V_ROWB + d * 64);
+                    vf4.w = *reinterpret_cast<const float*>(vr_ + 3 * C::V_ROWB + d * 64);
                     mma16<T>(__builtin_bit_cast(uint4, vf4), pfu, o[d]);
                 }
             }
         }
+        // ---- hand the next tile over ----
+        if constexpr (C::PIPE) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) ATTN_STORE_KV(cur ^ 1);
+            __syncthreads();
+        } else {
+            __syncthreads();   // everyone done with the single buffer
+            if (more) ATTN_STAGE_DIRECT(k0 + C::BKV);
+            __syncthreads();
+        }
     }
+#undef ATTN_LOAD_KV
+#undef ATTN_STORE_KV
+#undef ATTN_STAGE_DIRECT
 
     // ---- finish: total row sum over the 4 lane groups, normalise, store 4 consecutive d ----
     l_run += __shfl_xor(l_run, 16);
@@ -234,12 +352,19 @@ extern "C" int madm_attention_fwd(const madm_attention_args* a, void* stream) {
     p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo;
     p.B = a->B; p.H = a->H; p.Lq = a->Lq; p.Lk = a->Lk; p.D = a->D;
     p.scale_log2 = a->scale * 1.44269504088896340736f;
+    {
+        const size_t rows = (size_t)a->B * a->Lk;
+        const size_t bk = ((rows - 1) * a->ldk + (size_t)a->H * a->D) * es;
+        const size_t bv = ((rows - 1) * a->ldv + (size_t)a->H * a->D) * es;
+        MADM_REQUIRE(bk < 0x80000000ull && bv < 0x80000000ull, "attention: K/V views must stay below 2 GiB");
+        p.bytes_k = (unsigned)bk; p.bytes_v = (unsigned)bv;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (a->dtype == MADM_BF16) {
         switch (a->D) {
-            case 40: return launch_attn<bf16_t, 2, 3, 4, 4>(p, s);
+            case 40: return a->Lk >= 512 ? launch_attn<bf16_t, 2, 3, 4, 8>(p, s) : launch_attn<bf16_t, 2, 3, 4, 4>(p, s);
             case 64: return launch_attn<bf16_t, 2, 4, 4, 4>(p, s);
-            case 80: return launch_attn<bf16_t, 3, 5, 4, 4>(p, s);
+            case 80: return a->Lk >= 512 ? launch_attn<bf16_t, 3, 5, 4, 8>(p, s) : launch_attn<bf16_t, 3, 5, 4, 4>(p, s);
             case 160: return launch_attn<bf16_t, 5, 10, 4, 4>(p, s);
             case 512: return launch_attn<bf16_t, 16, 32, 2, 2>(p, s);
             default: break;

@@ -12,7 +12,7 @@
 
 namespace {
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NST>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;            // elements per K tile (128 B per row)
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     const int IWe = p.upsample ? 2 * p.IW : p.IW;
     const int ush = p.upsample ? 1 : 0;
 
-    u32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];   // two register stages: loads run two K-tiles ahead
+    u32x4 ra[NST][RA], rb[NST][RB];   // NST register stages: the global loads run NST K-tiles ahead of the MFMAs
 
 #define IGEMM_LOAD_TILE(kt, RA_, RB_)                                                                    \
     {                                                                                            \
@@ -117,13 +117,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Pipeline: LDS buffer (t & 1) holds tile t; register stage 0/1 holds tile t+1; the loads of tile
-    // t+2 are issued before the MFMAs of tile t and get two MFMA phases to land.
-    if (kt0 < kt1) {
-        IGEMM_LOAD_TILE(kt0, ra0, rb0);
-        if (kt0 + 1 < kt1) IGEMM_LOAD_TILE(kt0 + 1, ra1, rb1);
-        IGEMM_STORE_TILE(0, ra0, rb0);
-    }
+    // Pipeline: LDS buffer ((t - kt0) & 1) holds tile t; register stage (t + j) % NST holds tile t + j for
+    // j = 1 .. NST-1; the loads of tile t + NST are issued before the MFMAs of tile t into the stage that held
+    // tile t, and get NST MFMA phases to land (small grids have no co-resident block to hide the latency).
+#pragma unroll
+    for (int u = 0; u < NST; ++u)
+        if (kt0 + u < kt1) IGEMM_LOAD_TILE(kt0 + u, ra[u], rb[u]);
+    if (kt0 < kt1) IGEMM_STORE_TILE(0, ra[0], rb[0]);
     __syncthreads();
 
     const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
@@ -142,23 +142,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
                 _Pragma("unroll") for (int j = 0; j < NI; ++j) mma16<T>(wf[j], af[i], acc[i][j]);   \
         }                                                                                           \
     }
-    // one step: tile kt is in LDS buffer CUR, tile kt+1 in registers (RS_A/RS_B); tile kt+2 -> (RL_A/RL_B)
-#define IGEMM_STEP(kt, CUR, RL_A, RL_B, RS_A, RS_B)                                                 \
-    {                                                                                               \
-        if ((kt) + 2 < kt1) IGEMM_LOAD_TILE((kt) + 2, RL_A, RL_B);                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-        IGEMM_COMPUTE(CUR);                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
-        if ((kt) + 1 < kt1) IGEMM_STORE_TILE((CUR) ^ 1, RS_A, RS_B);                                \
-        __syncthreads();                                                                            \
+    for (int kt = kt0; kt < kt1; kt += NST) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int t = kt + u;
+            if (t < kt1) {
+                const int cur = (t - kt0) & 1;
+                if (t + NST < kt1) IGEMM_LOAD_TILE(t + NST, ra[u], rb[u]);            // stage u held tile t (in LDS now)
+                __builtin_amdgcn_sched_barrier(0);
+                IGEMM_COMPUTE(cur);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < kt1) IGEMM_STORE_TILE(cur ^ 1, ra[(u + 1) % NST], rb[(u + 1) % NST]);
+                __syncthreads();
+            }
+        }
     }
-    int kt = kt0;
-    for (; kt + 1 < kt1; kt += 2) {
-        IGEMM_STEP(kt, 0, ra0, rb0, ra1, rb1);       // loads t+2 -> stage 0 (free), stores stage 1 (t+1)
-        IGEMM_STEP(kt + 1, 1, ra1, rb1, ra0, rb0);   // loads t+3 -> stage 1, stores stage 0 (t+2)
-    }
-    if (kt < kt1) IGEMM_STEP(kt, 0, ra0, rb0, ra1, rb1);
-#undef IGEMM_STEP
 #undef IGEMM_COMPUTE
 #undef IGEMM_LOAD_TILE
 #undef IGEMM_STORE_TILE
@@ -393,9 +391,9 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
         p.tilesN = (p.N + bn - 1) / bn;
         const int tilesM = (p.M + bm - 1) / bm;
         dim3 grid((unsigned)(tilesM * p.tilesN), 1, (unsigned)p.splitk);
-        if (t == 1) igemm_kernel<T, 128, 128><<<grid, 256, 0, s>>>(p);
-        else if (t == 2) igemm_kernel<T, 128, 64><<<grid, 256, 0, s>>>(p);
-        else igemm_kernel<T, 64, 64><<<grid, 256, 0, s>>>(p);
+        if (t == 1) igemm_kernel<T, 128, 128, 2><<<grid, 256, 0, s>>>(p);
+        else if (t == 2) igemm_kernel<T, 128, 64, 3><<<grid, 256, 0, s>>>(p);
+        else igemm_kernel<T, 64, 64, 4><<<grid, 256, 0, s>>>(p);
         rc = madm_check_launch("igemm_kernel");
     }
     if (rc) return rc;

@@ -63,35 +63,39 @@ template <typename T>
 __global__ __launch_bounds__(256) void image_to_im2col_kernel(const float* __restrict__ img, T* __restrict__ out,
                                                               int B, int H, int W, int Kpad, float mean,
                                                               float inv_std, float* minmax) {
+    // one thread per pixel: 27 (L1/L2-resident) neighbour reads, one full Kpad*sizeof(T)-byte row written
     constexpr int EPC = TT<T>::EPC;
-    const unsigned CPR = (unsigned)Kpad / EPC;
     const unsigned HW = (unsigned)H * W;
-    const unsigned total = (unsigned)B * HW * CPR;   // < 2^31 (checked by the launcher)
+    const unsigned total = (unsigned)B * HW;
     float lo = INFINITY, hi = -INFINITY;
-    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const unsigned q = idx % CPR;
-        const unsigned pix = idx / CPR;
+    for (unsigned pix = blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += gridDim.x * blockDim.x) {
         const unsigned b = pix / HW;
         const unsigned rem = pix - b * HW;
         const int y = (int)(rem / (unsigned)W), x = (int)(rem - (rem / (unsigned)W) * (unsigned)W);
         const float* ib = img + (size_t)b * 3 * HW;
-        float f[EPC];
+        float v[32];
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) {
-            const int k = (int)q * EPC + j;
-            float v = 0.f;
-            if (k < 27) {
-                const int tap = k / 3, c = k - tap * 3;
-                const int r = tap / 3, s2 = tap - r * 3;
+        for (int k = 27; k < 32; ++k) v[k] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
                 const int yy = y + r - 1, xx = x + s2 - 1;
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-                    v = (ib[(unsigned)c * HW + (unsigned)yy * W + xx] - mean) * inv_std;
-                    if (tap == 4) { lo = fminf(lo, v); hi = fmaxf(hi, v); }
+                const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float t = 0.f;
+                    if (ok) t = (ib[(unsigned)c * HW + (unsigned)yy * W + xx] - mean) * inv_std;
+                    v[(r * 3 + s2) * 3 + c] = t;
                 }
             }
-            f[j] = v;
-        }
-        *reinterpret_cast<uint4*>(out + (size_t)idx * EPC) = f32_to_chunk<T>(f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lo = fminf(lo, v[12 + c]); hi = fmaxf(hi, v[12 + c]); }
+        T* o = out + (size_t)pix * Kpad;
+#pragma unroll
+        for (int q = 0; q < 32 / EPC; ++q) *reinterpret_cast<uint4*>(o + q * EPC) = f32_to_chunk<T>(v + q * EPC);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int q = 32 / EPC; q < Kpad / EPC; ++q) *reinterpret_cast<uint4*>(o + q * EPC) = z;
     }
     if (minmax) block_minmax(lo, hi, minmax);
 }
@@ -235,8 +239,9 @@ int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H
     MADM_REQUIRE(B > 0 && H > 0 && W > 0 && Kpad >= 27 && Kpad % epc == 0, "image_to_im2col3x3: bad dims");
     MADM_REQUIRE(std != 0.f, "image_to_im2col3x3: std == 0");
     hipStream_t s = (hipStream_t)stream;
-    const size_t total = (size_t)B * H * W * (Kpad / epc);
-    MADM_REQUIRE(total < 0x7fffffffull, "image_to_im2col3x3: tensor too large for 32-bit indexing");
+    MADM_REQUIRE(Kpad >= 32, "image_to_im2col3x3: Kpad must be at least 32");
+    const size_t total = (size_t)B * H * W;
+    MADM_REQUIRE(total * Kpad < 0x7fffffffull, "image_to_im2col3x3: tensor too large for 32-bit indexing");
     MADM_DISPATCH_DTYPE(dtype, (image_to_im2col_kernel<T><<<grid_for(total, 2048), 256, 0, s>>>(
                                    img, (T*)out, B, H, W, Kpad, mean, 1.0f / std, minmax)));
     return madm_check_launch("image_to_im2col_kernel");
