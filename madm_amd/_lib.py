@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmadm_hip.so")
+LIB_PATH = os.environ.get("MADM_HIP_LIB") or os.path.join(_HERE, "libmadm_hip.so")   # env override: A/B kernel builds
 
 MADM_F32 = 0
 MADM_BF16 = 1

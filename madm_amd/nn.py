@@ -124,7 +124,10 @@ class Conv2d(_Packed):
         dtype = x.t.dtype
         gn = None
         if norm is not None:
-            if ops.can_fuse_groupnorm(x.H, x.W, self.kernel_size, self.stride, self.padding, self.asym_pad, upsample):
+            # folding the norm into the conv re-applies it once per 128-channel output tile: it pays only when the
+            # conv has a single output tile (measured on MI355X; wider layers run gn_apply once + the plain conv)
+            if self.out_channels <= ops.FUSE_GN_MAX_N and ops.can_fuse_groupnorm(
+                    x.H, x.W, self.kernel_size, self.stride, self.padding, self.asym_pad, upsample):
                 srcs = [x] if x2 is None else [x, x2]
                 sts = []
                 for s_ in srcs:
