@@ -49,7 +49,9 @@ PROFILE = None
 CAPTURE = None   # tools/tune_conv.py: when a list, conv2d appends (args struct, tensors kept alive, desc)
 _TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64", 4: "conv3x3_halo_x128", 5: "conv3x3_halo_x64"}
 FUSE_GN = True   # fold GroupNorm(+SiLU) into eligible 3x3 convs (debug switch)
-FUSE_GN_MAX_N = 128   # ... whose output fits one 128-channel tile (wider: the transform would be redone per tile)
+import os as _os
+FUSE_GN_MAX_N = int(_os.environ.get("MADM_FUSE_GN_MAX_N", "128"))   # ... whose output fits one 128-channel tile
+# (wider layers would redo the transform once per output tile; env override for A/B runs)
 
 
 def can_fuse_groupnorm(IH, IW, KH, stride, pad, asym_pad, upsample):

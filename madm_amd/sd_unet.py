@@ -142,9 +142,12 @@ class Attention(nn.Module):
             self.__dict__[key] = f
         return f
 
-    def forward(self, x, B, L, ctx=None, Lk=None, residual=None):
-        """x: [B*L, C] normalised tokens; ctx: [B*Lk, 768] for cross attention; returns
-        to_out(attn) + residual."""
+    def has_active_lora_kv(self):
+        return any(isinstance(m, LoraLinear) and m.active() for m in (self.to_k, self.to_v))
+
+    def forward(self, x, B, L, ctx=None, Lk=None, residual=None, kv=None):
+        """x: [B*L, C] normalised tokens; ctx: [B*Lk, 768] for cross attention (or ``kv`` = the precomputed
+        [B*Lk, 2C] view of the UNet-wide batched K/V projection); returns to_out(attn) + residual."""
         C = self.heads * self.dim_head
         if not self.is_cross:
             qkv = self._fused("_f_qkv", ("to_q", "to_k", "to_v"))(x)
@@ -152,10 +155,20 @@ class Attention(nn.Module):
             Lk = L
         else:
             q = self._fused("_f_q", ("to_q",))(x)
-            kv = self._fused("_f_kv", ("to_k", "to_v"))(ctx)
+            if kv is None:
+                kv = self._fused("_f_kv", ("to_k", "to_v"))(ctx)
             k, v = kv[:, :C], kv[:, C:]
         o = ops.attention(q, k, v, B, self.heads, L, Lk, self.dim_head, self.scale)
         return self._fused("_f_out", ("to_out",))(o, residual=residual)
+
+
+class CtxKV:
+    """The prompt tokens plus the K/V projections of EVERY cross-attention layer, computed by one GEMM per
+    forward (the context and the to_k / to_v weights do not depend on the layer's activations):
+    kv[id(attn2)] = [B*Lk, 2C_layer] column view of ctx @ [Wk_1; Wv_1; Wk_2; ...]^T."""
+
+    def __init__(self, t, kv):
+        self.t, self.kv = t, kv
 
 
 class GEGLU(_Packed):
@@ -196,7 +209,8 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, h, B, L, ctx, Lk):
         h = self.attn1(self.norm1(h), B, L, residual=h)
-        h = self.attn2(self.norm2(h), B, L, ctx=ctx, Lk=Lk, residual=h)
+        kv = ctx.kv.get(id(self.attn2)) if isinstance(ctx, CtxKV) else None
+        h = self.attn2(self.norm2(h), B, L, ctx=ctx.t if isinstance(ctx, CtxKV) else ctx, Lk=Lk, residual=h, kv=kv)
         h = self.ff(self.norm3(h), residual=h)
         return h
 
@@ -405,6 +419,37 @@ class UNet2DConditionModel(nn.Module):
             out.extend(blk.resnets)
         return out
 
+    def _cross_attentions(self):
+        out = []
+        for blk in list(self.down_blocks) + [self.mid_block] + list(self.up_blocks):
+            for tr in getattr(blk, "attentions", []):
+                for tb in tr.transformer_blocks:
+                    out.append(tb.attn2)
+        return out
+
+    def _ctx_kv(self, ctx):
+        """One GEMM for the K/V projections of all 16 cross-attention layers (skipped -> per-layer GEMMs when a
+        LoRA adapter is active on any to_k / to_v, whose side GEMM is layer-specific)."""
+        attns = self._cross_attentions()
+        if any(a.has_active_lora_kv() for a in attns):
+            return ctx
+        cache = self.__dict__.setdefault("_ctxkv_cache", {})
+        ws = [p for a in attns for p in (_base(a.to_k).weight, _base(a.to_v).weight)]
+        ver = tuple((w._version, w.data_ptr()) for w in ws)
+        hit = cache.get(ctx.dtype)
+        if hit is None or hit[0] != ver:
+            with torch.no_grad():
+                W = torch.cat([w.detach().float() for w in ws], 0)
+                hit = (ver, packing.pack_linear_weight(W, ctx.dtype, ops.k_tile(ctx.dtype)))
+            cache[ctx.dtype] = hit
+        allkv = ops.linear(ctx, hit[1])
+        kv, off = {}, 0
+        for a in attns:
+            n = 2 * a.heads * a.dim_head
+            kv[id(a)] = allkv[:, off:off + n]
+            off += n
+        return CtxKV(ctx, kv)
+
     def _time_rows(self, emb):
         """emb: [B, 1280] (compute dtype).  Returns one f32 [B, C_r] view per resnet:
         time_emb_proj_r(silu(emb)) for every ResnetBlock2D, from ONE GEMM over the stacked weights."""
@@ -445,6 +490,7 @@ class UNet2DConditionModel(nn.Module):
         res = None if cond_emb is None else ops.cast_from_f32(cond_emb.contiguous(), dtype)
         emb = self.time_embedding(t_emb, residual=res)
         rows = self._time_rows(emb)
+        ctx = self._ctx_kv(ctx)
 
         h = self.conv_in(sample)
         skips = [h]
