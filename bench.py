@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lora", action="store_true", help="enable one r=8 LoRA adapter (north_star variant)")
+    ap.add_argument("--workload", default="extract", choices=["extract", "eval"],
+                    help="extract = BASELINE configs[1] (the metric); eval = configs[2]: full meta-arch inference "
+                         "(VAE decoder + projections + DAFormer head, RGB->Depth config, batch 1) -- informational")
     return ap.parse_args()
 
 
@@ -52,16 +55,42 @@ def make_inputs(B, size, device):
             "cond_emb": torch.zeros((B, 1, 1280), device=device)}
 
 
+def build_eval_model(dtype, device):
+    """BASELINE configs[2]: the shipped RGB->Depth inference graph (mtmadise_cityscapes_rgb_to_depth_11.py)."""
+    from madm_amd.ldm_rocm import LdmRocm
+    from madm_amd.backbone import BasePromptTimeGenerator, AttentionFeatureExtractorBackbone
+    from madm_amd.head import DAFormerHead
+    from madm_amd.meta_arch import MadmInference
+    from madm_amd import weights
+    ldm = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=(),
+                  input_range='-1+1', unet_block_indices_type='after', finetune_unet='no', compute_dtype=dtype,
+                  weights='synthetic', seed=0, vae_decoder_loss=True, device=device)
+    gen = BasePromptTimeGenerator(learnable_cond_prompt=True, learnable_cond_time=True, clip_state='no', num_timesteps=1,
+                                  ldm_extractor=ldm, same_cond_params=True)
+    backbone = AttentionFeatureExtractorBackbone(
+        attention_features_res=None, feature_dims=[3, 320, 640, 1280], projection_dim=[128, 512, 512, 512],
+        attention_features_location=None, feature_extractor=gen, num_res_blocks=1, out_features=["s0", "s3", "s4", "s5"])
+    head = DAFormerHead(in_channels=[128, 512, 512, 512], in_keys=["s0", "s3", "s4", "s5"], in_index=[0, 1, 2, 3], channels=256,
+                        dropout_ratio=0.1, num_classes=11, norm_cfg=dict(type='BN'), align_corners=False,
+                        decoder_params=dict(embed_dims=256, embed_cfg=dict(type='mlp'), embed_neck_cfg=dict(type='mlp'),
+                                            fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False)))
+    for prefix, mod in (("backbone.feature_projections.", backbone.feature_projections),
+                        ("backbone.clip_project_rgb.", gen.clip_project_rgb), ("head.", head)):
+        weights.synth_init_(mod, 0, prefix)
+        weights.synth_buffers_(mod, 0, prefix)
+    return MadmInference(backbone.to(device), head.to(device), target_modality="Depth").eval()
+
+
 def kernel_profile(model, inputs):
     """Eager pass with HIP events around every MFMA-kernel launch (events recorded on the launch
     stream).  Returns {kernel: (launches, total_ms, algorithmic_flops)}."""
     from madm_amd import ops
     for _ in range(2):
-        model(inputs, "rgb")
+        model(*inputs)
     torch.cuda.synchronize()
     ops.PROFILE = []
     try:
-        model(inputs, "rgb")
+        model(*inputs)
         torch.cuda.synchronize()
         rec = ops.PROFILE
     finally:
@@ -128,6 +157,13 @@ def main():
 
     from madm_amd.ldm_rocm import LdmRocm
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.workload == "eval":
+        args.batch = 1
+        model = build_eval_model(dtype, device)
+        ldm = model.backbone.feature_extractor.ldm_extractor
+        call = ([{"target_second_modality": 255.0 * torch.rand((3, args.size, args.size),
+                                                                generator=torch.Generator().manual_seed(777)).to(device)}],)
+        return run(args, model, call, ldm, rank, world, device, dist, mdist)
     model = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=[],
                     input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
                     compute_dtype=dtype, weights='synthetic', seed=0, device=device)
@@ -139,29 +175,32 @@ def main():
         model.unet.set_adapter(["Depth"])
         weights.randomize_lora_B_(model.unet)
     inputs = make_inputs(args.batch, args.size, device)
+    return run(args, model, (inputs, "rgb"), model, rank, world, device, dist, mdist)
 
+
+def run(args, model, call, ldm, rank, world, device, dist, mdist):
     # eager warm-up: packs weights, sizes workspaces, checks the input range once
-    model(inputs, "rgb")
+    model(*call)
     torch.cuda.synchronize()
-    model.check_input_range = False
+    ldm.check_input_range = False
 
     prof = None
     if rank == 0 and not args.no_kernel_profile:
-        prof = kernel_profile(model, inputs)
+        prof = kernel_profile(model, call)
 
     if args.no_graph:
         def step():
-            return model(inputs, "rgb")
+            return model(*call)
     else:
         graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            model(inputs, "rgb")
+            model(*call)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.cuda.graph(graph):
-            static_out = model(inputs, "rgb")
+            static_out = model(*call)
 
         def step():
             graph.replay()
@@ -189,20 +228,24 @@ def main():
         images = args.batch * world * args.steps
         value = images / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        alg = ALG_FLOP_PER_IMAGE if args.workload == "extract" else 6.34725e12   # full eval forward
         out = {
-            "metric": "UNet feature-extract images/sec @512x512 bs=2/GPU",
+            "metric": "UNet feature-extract images/sec @512x512 bs=2/GPU" if args.workload == "extract"
+            else "full meta-arch eval images/sec @512x512 bs=1 (configs[2], informational)",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: SD-v1-4 VAE-encode + UNet single-timestep feature extractor "
-                                   f"(taps 5,8,11 'after'), {args.batch}x3x{args.size}x{args.size} per GPU, t=0, "
-                                   "LoRA " + ("r=8 on" if args.lora else "off (shipped configs)") +
-                                   ", seeded synthetic weights",
+            "config": {"workload": ("configs[1]: SD-v1-4 VAE-encode + UNet single-timestep feature extractor "
+                                    f"(taps 5,8,11 'after'), {args.batch}x3x{args.size}x{args.size} per GPU, t=0, "
+                                    "LoRA " + ("r=8 on" if args.lora else "off (shipped configs)") +
+                                    ", seeded synthetic weights") if args.workload == "extract" else
+                       ("configs[2]: full MADM inference forward, RGB->Depth config (VAE enc -> UNet -> VAE dec -> "
+                        f"GN projections -> DAFormer head @512x512, K=11), 1x3x{args.size}x{args.size} per GPU"),
                        "global_batch": args.batch * world, "parallelism": f"replicas x{world} (no collectives)",
                        "launch": "eager" if args.no_graph else "hipGraph replay"},
             "device_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 4),
-            "whole_path_roofline_frac": round(value / world * ALG_FLOP_PER_IMAGE / (peak * 1e12), 4),
+            "whole_path_roofline_frac": round(value / world * alg / (peak * 1e12), 4),
         }
         if prof:
             dom = max(prof.items(), key=lambda kv: kv[1][1])
@@ -214,7 +257,7 @@ def main():
             out["kernels"] = {k: {"launches": v[0], "ms": round(v[1], 4),
                                   "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None}
                               for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "extract":
             out["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(out), flush=True)
     if dist is not None:

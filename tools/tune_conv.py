@@ -18,20 +18,25 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--workload", default="extract", choices=["extract", "eval"])
     args = ap.parse_args()
     from madm_amd.ldm_rocm import LdmRocm
     from madm_amd import ops
     from madm_amd._lib import lib, Conv2dArgs
     import bench
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    m = LdmRocm("", [], [5, 8, 11], [], input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
-                compute_dtype=dtype, weights='synthetic', seed=0)
-    inputs = bench.make_inputs(args.batch, args.size, torch.device("cuda"))
-    m(inputs, "rgb")
+    if args.workload == "eval":
+        m = bench.build_eval_model(dtype, torch.device("cuda"))
+        call = ([{"target_second_modality": 255.0 * torch.rand((3, args.size, args.size)).cuda()}],)
+    else:
+        m = LdmRocm("", [], [5, 8, 11], [], input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
+                    compute_dtype=dtype, weights='synthetic', seed=0)
+        call = (bench.make_inputs(args.batch, args.size, torch.device("cuda")), "rgb")
+    m(*call)
     torch.cuda.synchronize()
     lib.madm_debug_set_conv_tile(-1)   # heuristic only (ignore the tuned table) while capturing
     ops.CAPTURE = []
-    m(inputs, "rgb")
+    m(*call)
     torch.cuda.synchronize()
     cap = ops.CAPTURE
     ops.CAPTURE = None
