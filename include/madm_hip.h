@@ -260,10 +260,20 @@ int madm_resize_bilinear(int dtype, const void* in, int ldi, void* out, int ldo,
 /* the same on `planes` NCHW f32 planes (backbone preprocess_image T.Resize, feature_extractor.py:77-79,140-146). */
 int madm_resize_bilinear_nchw_f32(const float* in, float* out, int planes, int IH, int IW, int OH, int OW,
                                   void* stream);
-/* out[pl][y][x] = (y < IH && x < IW) ? in[pl][y][x] * scale : 0 on `planes` f32 planes: "/255" + the zero padding
- * of ImageList.from_tensors (OH >= IH; mtmadise.py:668-670) or the final crop to the original size (OH <= IH; :688). */
-int madm_scale_pad_crop_nchw_f32(const float* in, float* out, int planes, int IH, int IW, int OH, int OW,
-                                 float scale, void* stream);
+/* out[pl][y][x] = in[pl][y1 + y][x1 + x] * scale inside the input, 0 outside, on `planes` f32 planes: "/255" + the
+ * zero padding of ImageList.from_tensors (mtmadise.py:668-670), the final crop to the original size (:688) and the
+ * sliding-window crops img[:, :, y1:y2, x1:x2] (feature_extractor.py:250). */
+int madm_scale_pad_crop_nchw_f32(const float* in, float* out, int planes, int IH, int IW, int y1, int x1,
+                                 int OH, int OW, float scale, void* stream);
+/* sliding-window inference (feature_extractor.py:199-278): averages the nW (<= 4) windows' feature maps
+ * win[nW][B][h][w][C] into the canvas out[B][h][Wc][C]; window k covers canvas columns [x1[k], x1[k] + w)
+ * (x1 = host array); every canvas column is divided by the number of windows covering it. */
+int madm_slide_merge(int dtype, const void* win, void* out, int nW, int B, int h, int w, int Wc, int C,
+                     const int* x1, void* stream);
+/* conf[(K+1) * pred[i] + gt'[i]] += 1, gt' = K where gt == ignore_label (int64 counters, caller-zeroed or running):
+ * DSECSemSegEvaluator.process (evaluation/d2_evaluator.py:106-127); exact integer arithmetic. */
+int madm_confusion_matrix(const int64_t* pred, const int64_t* gt, size_t n, int num_classes, int ignore_label,
+                          int64_t* conf, void* stream);
 /* depthwise 3x3 conv (dilation d, padding d, stride 1) on channels-last x [B*H*W][C] with w [9][C] f32
  * (tap-major), then y = act(acc * scale[c] + shift[c]) (scale/shift = eval-mode BatchNorm folded):
  * mmcv DepthwiseSeparableConvModule.depthwise_conv of the sep-ASPP (daformer_head.py:383-398). */

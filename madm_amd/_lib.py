@@ -102,7 +102,10 @@ SYMBOLS = [
     ("madm_resize_bilinear", c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p]),
     ("madm_resize_bilinear_nchw_f32", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    ("madm_scale_pad_crop_nchw_f32", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    ("madm_scale_pad_crop_nchw_f32", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                             c_void_p]),
+    ("madm_slide_merge", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    ("madm_confusion_matrix", c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
     ("madm_dwconv3x3", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_void_p]),
     ("madm_tanh_gate", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),

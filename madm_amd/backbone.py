@@ -211,8 +211,10 @@ class FeatureExtractorBackbone(nn.Module):
         super().__init__()
         self.feature_extractor = feature_extractor
         self.use_checkpoint = use_checkpoint
-        if slide_inference or slide_training:
-            raise NotImplementedError("sliding-window inference (feature_extractor.py:199-278) is SURVEY.md 8f rank 4")
+        if slide_training:
+            raise NotImplementedError("slide_training needs the training path (not built)")
+        # sliding-window inference: three 512-wide windows over a 512 x 1024 input (feature_extractor.py:73-75)
+        self.y1_y2_x1_x2 = [(0, 512, 0, 512), (0, 512, 256, 768), (0, 512, 512, 1024)] if slide_inference else None
         if isinstance(projection_dim, int):
             self.feature_projections = nn.ModuleList()
             for feature_dim in self.feature_extractor.feature_dims:
@@ -275,8 +277,38 @@ class FeatureExtractorBackbone(nn.Module):
             return self.checkpoint_forward_features(features[0], input_image_size, ema_forward), features[1]
         return self.checkpoint_forward_features(features, input_image_size, ema_forward)
 
+    def slide_forward(self, img, input_modal='rgb', ema_forward=False, timestep=None, **kwargs):
+        """feature_extractor.py:199-278: the windows are cropped on the device, run as ONE batched forward
+        (images are independent units: GroupNorm / LayerNorm are per-sample) and their projected features are
+        averaged into the full-size canvas by madm_slide_merge (sum of the covering windows / their count)."""
+        if 'return_unet_final_output' in kwargs:
+            raise NotImplementedError("return_unet_final_output with sliding windows is a training-time combination")
+        B, _, h_img, w_img = img.shape
+        short = min(h_img, w_img)
+        wins = self.y1_y2_x1_x2
+        h_grids = max(h_img - short + short - 1, 0) // short + 1
+        w_grids = max(w_img - short + short - 1, 0) // short + 1 + 1
+        assert h_grids == 1 and w_grids == 3 == len(wins), "the reference supports exactly three windows (:233)"
+        img = img.float().contiguous()
+        crops = torch.empty((len(wins) * B, img.shape[1], short, short), dtype=torch.float32, device=img.device)
+        for k, (y1, y2, x1, x2) in enumerate(wins):
+            assert (y2 - y1, x2 - x1) == (short, short)
+            ops.scale_pad_nchw(img, 1.0, short, short, y1, x1, out=crops[k * B:(k + 1) * B])
+        feats = self.single_forward(crops, input_modal, ema_forward, timestep, **kwargs)['output_features']
+        out_tok = {}
+        for name, f in feats.tok.items():
+            stride = self._out_feature_strides[name]
+            assert f.B == len(wins) * B
+            merged = ops.slide_merge(f.t, len(wins), B, f.H, f.W, w_img // stride, [w[2] // stride for w in wins])
+            out_tok[name] = Tok(merged, B, h_img // stride, w_img // stride)
+        res = FeatureDict({k: v.nchw() for k, v in out_tok.items()})
+        res.tok = out_tok
+        return {'output_features': res}
+
     def forward(self, img, input_modal='rgb', ema_forward=False, timestep=None, **kwargs):
-        return self.single_forward(img, input_modal, ema_forward, timestep, **kwargs)
+        if not self._slide_inference:
+            return self.single_forward(img, input_modal, ema_forward, timestep, **kwargs)
+        return self.slide_forward(img, input_modal, ema_forward, timestep, **kwargs)
 
 
 class AttentionFeatureExtractorBackbone(FeatureExtractorBackbone):

@@ -109,17 +109,75 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
     }
 }
 
-// out[pl][y][x] = (y < IH && x < IW) ? in[pl][y][x] * scale : 0  -- zero padding (OH >= IH) or cropping (OH <= IH)
+// out[pl][y][x] = in[pl][y1 + y][x1 + x] * scale inside the input, 0 outside: zero padding, cropping, windows
 __global__ void scale_pad_crop_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int IH, int IW,
-                                      int OH, int OW, float scale) {
+                                      int y1, int x1, int OH, int OW, float scale) {
     const size_t total = (size_t)planes * OH * OW;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % OW);
+        const int x = (int)(idx % OW) + x1;
         const size_t t = idx / OW;
-        const int y = (int)(t % OH);
+        const int y = (int)(t % OH) + y1;
         const size_t pl = t / OH;
-        out[idx] = (y < IH && x < IW) ? in[(pl * IH + y) * IW + x] * scale : 0.f;
+        out[idx] = ((unsigned)y < (unsigned)IH && (unsigned)x < (unsigned)IW) ? in[(pl * IH + y) * IW + x] * scale : 0.f;
     }
+}
+
+// sliding-window merge (feature_extractor.py:199-278): the windows' feature maps [nW][B][h][w][C] (channels-last,
+// window-major) are averaged into the canvas [B][h][Wc][C]: out = sum_w win_w / count, window w covering columns
+// [x1[w], x1[w] + w) of the canvas
+template <typename T>
+__global__ __launch_bounds__(256) void slide_merge_kernel(const T* __restrict__ win, T* __restrict__ out, int nW, int B,
+                                                          int h, int w, int Wc, int C, int4 x1) {
+    constexpr int EPC = TT<T>::EPC;
+    const unsigned CPR = (unsigned)C / EPC;
+    const unsigned total = (unsigned)B * h * Wc * CPR;
+    const int xs[4] = {x1.x, x1.y, x1.z, x1.w};
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned q = idx % CPR;
+        const unsigned pix = idx / CPR;
+        const int X = (int)(pix % (unsigned)Wc);
+        const unsigned t = pix / (unsigned)Wc;
+        const int y = (int)(t % (unsigned)h);
+        const int b = (int)(t / (unsigned)h);
+        float acc[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) acc[j] = 0.f;
+        int cnt = 0;
+        for (int k = 0; k < nW; ++k) {
+            const int lx = X - xs[k];
+            if ((unsigned)lx < (unsigned)w) {
+                float f[EPC];
+                chunk_to_f32<T>(*reinterpret_cast<const uint4*>(win + ((((size_t)k * B + b) * h + y) * w + lx) * C + q * EPC), f);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) acc[j] += f[j];
+                ++cnt;
+            }
+        }
+        const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) acc[j] *= inv;
+        *reinterpret_cast<uint4*>(out + (size_t)pix * C + q * EPC) = f32_to_chunk<T>(acc);
+    }
+}
+
+// confusion matrix of the evaluator (evaluation/d2_evaluator.py:106-127): conf[(K+1) * pred + gt'] += 1 with
+// gt' = K where gt == ignore_label.  Per-block LDS histogram, 64-bit global counters: exact integer arithmetic.
+__global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restrict__ pred, const int64_t* __restrict__ gt,
+                                                        size_t n, int K, int ignore_label,
+                                                        unsigned long long* __restrict__ conf) {
+    extern __shared__ unsigned int hist[];
+    const int bins = (K + 1) * (K + 1);
+    for (int i = threadIdx.x; i < bins; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        long long g = gt[i];
+        if (g == ignore_label) g = K;
+        const long long p = pred[i];
+        if (p >= 0 && p <= K && g >= 0 && g <= K) atomicAdd(&hist[(K + 1) * (int)p + (int)g], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += blockDim.x)
+        if (hist[i]) atomicAdd(&conf[i], (unsigned long long)hist[i]);
 }
 
 __global__ void tanh_gate_kernel(const float* __restrict__ a1, const float* __restrict__ x1, const float* __restrict__ a2,
@@ -191,12 +249,35 @@ int madm_dwconv3x3(int dtype, const void* x, const float* w, const float* scale,
     return madm_check_launch("dwconv3x3_kernel");
 }
 
-int madm_scale_pad_crop_nchw_f32(const float* in, float* out, int planes, int IH, int IW, int OH, int OW, float scale,
-                                 void* stream) {
+int madm_scale_pad_crop_nchw_f32(const float* in, float* out, int planes, int IH, int IW, int y1, int x1, int OH, int OW,
+                                 float scale, void* stream) {
     MADM_REQUIRE(in && out && planes > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0, "scale_pad_crop: bad args");
-    scale_pad_crop_kernel<<<grid_for((size_t)planes * OH * OW), 256, 0, (hipStream_t)stream>>>(in, out, planes, IH, IW, OH,
-                                                                                             OW, scale);
+    scale_pad_crop_kernel<<<grid_for((size_t)planes * OH * OW), 256, 0, (hipStream_t)stream>>>(in, out, planes, IH, IW, y1,
+                                                                                             x1, OH, OW, scale);
     return madm_check_launch("scale_pad_crop_kernel");
+}
+
+int madm_slide_merge(int dtype, const void* win, void* out, int nW, int B, int h, int w, int Wc, int C, const int* x1,
+                     void* stream) {
+    MADM_REQUIRE(win && out && x1 && nW >= 1 && nW <= 4 && B > 0 && h > 0 && w > 0 && Wc >= w && C > 0, "slide_merge: bad args");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(C % epc == 0, "slide_merge: C must be a multiple of %d", epc);
+    const size_t total = (size_t)B * h * Wc * (C / epc);
+    MADM_REQUIRE(total < 0x7fffffffull, "slide_merge: tensor too large for 32-bit indexing");
+    int4 xs = make_int4(x1[0], nW > 1 ? x1[1] : 0, nW > 2 ? x1[2] : 0, nW > 3 ? x1[3] : 0);
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (slide_merge_kernel<T><<<grid_for(total), 256, 0, s>>>((const T*)win, (T*)out, nW, B, h, w, Wc,
+                                                                                   C, xs)));
+    return madm_check_launch("slide_merge_kernel");
+}
+
+int madm_confusion_matrix(const int64_t* pred, const int64_t* gt, size_t n, int num_classes, int ignore_label,
+                          int64_t* conf, void* stream) {
+    MADM_REQUIRE(pred && gt && conf && n > 0 && num_classes > 0 && num_classes < 100, "confusion_matrix: bad args");
+    const size_t shm = (size_t)(num_classes + 1) * (num_classes + 1) * sizeof(unsigned int);
+    confusion_kernel<<<grid_for(n, 1024), 256, shm, (hipStream_t)stream>>>(pred, gt, n, num_classes, ignore_label,
+                                                                           (unsigned long long*)conf);
+    return madm_check_launch("confusion_kernel");
 }
 
 int madm_tanh_gate(const float* a1, const float* x1, const float* a2, const float* x2, float* out, size_t n, int repeat,

@@ -506,17 +506,42 @@ def argmax_nchw(x):
     return out
 
 
-def scale_pad_nchw(x, scale, OH, OW):
-    """x * scale, zero-padded (bottom/right) to [B, C, OH, OW] (f32 NCHW)."""
-    _need_cuda(x)
+def scale_pad_nchw(x, scale, OH, OW, y1=0, x1=0, out=None):
+    """x[:, :, y1:y1+OH, x1:x1+OW] * scale with zeros outside x (f32 NCHW): padding, cropping, window extraction."""
+    _need_cuda(x, out)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
     B, C, IH, IW = x.shape
-    out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
-    check(lib.madm_scale_pad_crop_nchw_f32(x.data_ptr(), out.data_ptr(), B * C, IH, IW, OH, OW, float(scale), _stream()),
-          "madm_scale_pad_crop_nchw_f32")
+    if out is None:
+        out = torch.empty((B, C, OH, OW), dtype=torch.float32, device=x.device)
+    assert out.is_contiguous() and tuple(out.shape) == (B, C, OH, OW) and out.dtype == torch.float32
+    check(lib.madm_scale_pad_crop_nchw_f32(x.data_ptr(), out.data_ptr(), B * C, IH, IW, y1, x1, OH, OW, float(scale),
+                                           _stream()), "madm_scale_pad_crop_nchw_f32")
     return out
 
 
-def crop_nchw(x, OH, OW):
-    """x[:, :, :OH, :OW] as a dense tensor."""
-    return scale_pad_nchw(x, 1.0, OH, OW)
+def crop_nchw(x, OH, OW, y1=0, x1=0):
+    """x[:, :, y1:y1+OH, x1:x1+OW] as a dense tensor."""
+    return scale_pad_nchw(x, 1.0, OH, OW, y1, x1)
+
+
+def slide_merge(win, nW, B, h, w, Wc, x1):
+    """Averages window feature maps win [nW*B*h*w, C] (window-major) into the canvas [B*h*Wc, C]."""
+    _need_cuda(win)
+    assert win.is_contiguous() and win.shape[0] == nW * B * h * w and len(x1) == nW
+    out = torch.empty((B * h * Wc, win.shape[1]), dtype=win.dtype, device=win.device)
+    xs = (ctypes.c_int * nW)(*[int(v) for v in x1])
+    check(lib.madm_slide_merge(dtype_code(win), win.data_ptr(), out.data_ptr(), nW, B, h, w, Wc, win.shape[1], xs, _stream()),
+          "madm_slide_merge")
+    return out
+
+
+def confusion_matrix(pred, gt, num_classes, ignore_label, conf=None):
+    """conf[(K+1) * pred + gt'] += 1 (int64 [(K+1), (K+1)]), gt' = K where gt == ignore_label."""
+    _need_cuda(pred, gt, conf)
+    assert pred.dtype == torch.int64 and gt.dtype == torch.int64 and pred.numel() == gt.numel()
+    K = num_classes
+    if conf is None:
+        conf = torch.zeros((K + 1, K + 1), dtype=torch.int64, device=pred.device)
+    check(lib.madm_confusion_matrix(pred.contiguous().data_ptr(), gt.contiguous().data_ptr(), pred.numel(), K,
+                                    int(ignore_label), conf.data_ptr(), _stream()), "madm_confusion_matrix")
+    return conf

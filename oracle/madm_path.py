@@ -196,3 +196,52 @@ def eval_forward(backbone, head, image_0_255, eval_with_noise=None):
     out = head(feats)
     out = F.interpolate(out, size=t.shape[2:], mode='bilinear', align_corners=False)
     return out[:, :, :ori[0], :ori[1]], feats
+
+
+# ---- evaluator (evaluation/d2_evaluator.py:99-127, 240-275), numpy restatement -------------------------------------
+def evaluator_confusion(pred, gt, num_classes, ignore_label=255):
+    """pred / gt: int arrays; returns the (K+1) x (K+1) int64 confusion matrix exactly as the reference builds it."""
+    import numpy as np
+    pred = np.array(pred, dtype=np.int32)
+    gt = np.int32(np.array(gt)).copy()
+    gt[gt == ignore_label] = num_classes
+    n = num_classes + 1
+    return np.bincount(n * pred.reshape(-1) + gt.reshape(-1), minlength=n * n).reshape(n, n).astype(np.int64)
+
+
+def evaluator_metrics(conf, num_classes):
+    import numpy as np
+    acc = np.full(num_classes, np.nan, dtype=np.float64)
+    iou = np.full(num_classes, np.nan, dtype=np.float64)
+    tp = conf.diagonal()[:-1].astype(np.float64)
+    pos_gt = np.sum(conf[:-1, :-1], axis=0).astype(np.float64)
+    class_weights = pos_gt / np.sum(pos_gt)
+    pos_pred = np.sum(conf[:-1, :-1], axis=1).astype(np.float64)
+    acc_valid = pos_gt > 0
+    acc[acc_valid] = tp[acc_valid] / pos_gt[acc_valid]
+    iou_valid = (pos_gt + pos_pred) > 0
+    union = pos_gt + pos_pred - tp
+    iou[acc_valid] = tp[acc_valid] / union[acc_valid]
+    return {"mIoU": 100 * np.sum(iou[acc_valid]) / np.sum(iou_valid),
+            "fwIoU": 100 * np.sum(iou[acc_valid] * class_weights[acc_valid]),
+            "mACC": 100 * np.sum(acc[acc_valid]) / np.sum(acc_valid), "pACC": 100 * np.sum(tp) / np.sum(pos_gt),
+            "iou": iou, "acc": acc}
+
+
+def slide_forward(backbone, img):
+    """feature_extractor.py:199-278 on an OracleBackbone: three 512-wide windows over a 512 x 1024 input, features summed
+    into the canvas and divided by the per-pixel window count."""
+    wins = [(0, 512, 0, 512), (0, 512, 256, 768), (0, 512, 512, 1024)]
+    B, _, h_img, w_img = img.shape
+    out, cnt = {}, {}
+    for (y1, y2, x1, x2) in wins:
+        feats = backbone(img[:, :, y1:y2, x1:x2], input_modal='others')['output_features']
+        for k, f in feats.items():
+            s = backbone._strides[k]
+            if k not in out:
+                out[k] = torch.zeros((B, f.shape[1], h_img // s, w_img // s))
+                cnt[k] = torch.zeros_like(out[k])
+            out[k][:, :, y1 // s:y2 // s, x1 // s:x2 // s] += f
+            cnt[k][..., y1 // s:y2 // s, x1 // s:x2 // s] += 1
+    assert all((c == 0).sum() == 0 for c in cnt.values())
+    return {'output_features': {k: out[k] / cnt[k] for k in out}}

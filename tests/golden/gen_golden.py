@@ -106,7 +106,33 @@ def main_eval():
         print(f"{name}: {time.time() - t0:.1f}s", {k: v.shape for k, v in out.items()})
 
 
+def main_slide():
+    """Sliding-window inference (feature_extractor.py:199-278), 1 x 3 x 512 x 1024 input, s3/s4/s5 features.
+    NOTE: the reference's own slide_forward cannot run on its AttentionFeatureExtractorBackbone -- `channel =
+    self._out_feature_channels[k]` is the projection_dim LIST there (feature_extractor.py:111,208-214 ->
+    "TypeError: zeros(): argument 'size' ... got list", reproduced in this container) -- so this vector comes from the
+    oracle's restatement of the documented algorithm (oracle/madm_path.slide_forward), not from the reference class."""
+    from oracle import madm_path
+    vae, unet = build_oracle(lora=False)
+    torch.set_num_threads(os.cpu_count())
+    cfg = madm_path.S345_CFG
+    backbone, head = madm_path.build_oracle_eval_model(vae, unet, cfg)
+    init_eval_params(backbone, head)
+    img = torch.rand((1, 3, 512, 1024), generator=torch.Generator().manual_seed(778))
+    t0 = time.time()
+    with torch.no_grad():
+        feats = madm_path.slide_forward(backbone, img)['output_features']
+    out = {}
+    for k, f in feats.items():
+        out["feat_" + k] = f[:, ::8].contiguous().numpy()
+        out["feat_" + k + "_shape"] = np.array(f.shape, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "slide_s345.npz"), **out)
+    print(f"slide_s345: {time.time() - t0:.1f}s", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    if "slide_s345" in sys.argv[1:] or not sys.argv[1:]:
+        main_slide()
     if not sys.argv[1:] or any(a in CASES for a in sys.argv[1:]):
         main()
     if not sys.argv[1:] or any(a in EVAL_CASES for a in sys.argv[1:]):

@@ -182,3 +182,67 @@ def model_input(model, img):
     H, W = img.shape[1:]
     Hp, Wp = (H + 63) // 64 * 64, (W + 63) // 64 * 64
     return ops.scale_pad_nchw(img[None].cuda().contiguous(), 1 / 255.0, Hp, Wp)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_sliding_window_backbone(cuda, dtype):
+    """slide_inference (feature_extractor.py:199-278): three 512-wide windows of a 512 x 1024 image as one batched forward,
+    features averaged by window count.  Vector from the oracle restatement (the reference's slide_forward raises a
+    TypeError on its own Attention backbone, see tests/golden/gen_golden.py::main_slide)."""
+    from madm_amd.ldm_rocm import LdmRocm
+    from madm_amd.backbone import BasePromptTimeGenerator, AttentionFeatureExtractorBackbone
+    from madm_amd.head import DAFormerHead
+    from oracle import madm_path
+    from madm_amd import ops
+    cfg = madm_path.S345_CFG
+    ldm = LdmRocm("", [], [5, 8, 11], (), input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
+                  compute_dtype=dtype, weights='synthetic', seed=0)
+    gen = BasePromptTimeGenerator(ldm_extractor=ldm, same_cond_params=True)
+    backbone = AttentionFeatureExtractorBackbone(None, list(cfg["feature_dims"]), None, feature_extractor=gen,
+                                                 out_features=list(cfg["out_features"]),
+                                                 projection_dim=list(cfg["projection_dim"]), slide_inference=True)
+    head = DAFormerHead(in_channels=[512] * 3, in_keys=cfg["out_features"], in_index=[0, 1, 2], channels=256, num_classes=11,
+                        decoder_params=madm_path.head_decoder_params())
+    init_eval_params(backbone, head)
+    backbone = backbone.cuda().eval()
+    img = torch.rand((1, 3, 512, 1024), generator=torch.Generator().manual_seed(778))
+    feats = backbone(img.cuda(), input_modal='others')['output_features']
+    gold = load_golden("slide_s345")
+    for k in ("s3", "s4", "s5"):
+        f = feats[k].cpu()
+        assert tuple(f.shape) == tuple(gold["feat_" + k + "_shape"].tolist())
+        e, l2 = rel_err(f[:, ::8], gold["feat_" + k])
+        assert (e < 1e-3) if dtype == torch.float32 else (l2 < 6e-2), (k, e, l2)
+    # the merge kernel on its own: counts 1 / 2 / 2 / 1 over the four 256-column bands at stride 8
+    w = torch.randn(3 * 2 * 4 * 64, 64)
+    m = ops.slide_merge(w.to(dtype).cuda(), 3, 2, 4, 64, 128, [0, 32, 64]).float().cpu().reshape(2, 4, 128, 64)
+    wq = w.to(dtype).float().reshape(3, 2, 4, 64, 64)
+    ref = torch.zeros(2, 4, 128, 64); cnt = torch.zeros(1, 1, 128, 1)
+    for k, x1 in enumerate([0, 32, 64]):
+        ref[:, :, x1:x1 + 64] += wq[k]; cnt[:, :, x1:x1 + 64] += 1
+    assert rel_err(m, ref / cnt)[0] < (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+def test_device_evaluator_is_bit_exact(cuda):
+    """argmax -> confusion matrix -> mIoU on the device against the numpy restatement of
+    evaluation/d2_evaluator.py:106-127,246-270 (integer work: bit-exact; metrics: float64-equal)."""
+    import numpy as np
+    from madm_amd.evaluation import SemSegEvaluator
+    from oracle import madm_path
+    K = 11
+    g = torch.Generator().manual_seed(5)
+    ev = SemSegEvaluator(K, ignore_label=255)
+    conf_ref = np.zeros((K + 1, K + 1), dtype=np.int64)
+    for i in range(3):
+        logits = torch.randn((1, K, 97, 131), generator=g)
+        logits[0, 2, 5, 5] = logits[0, 9, 5, 5] = 50.0                      # tie -> first maximal class
+        gt = torch.randint(0, K, (1, 97, 131), generator=g)
+        gt[0, :7] = 255                                                        # ignored rows
+        ev.process([{"target_label": gt}], [{"sem_seg": logits.cuda()}])
+        conf_ref += madm_path.evaluator_confusion(logits[0].argmax(dim=0).numpy(), gt[0].numpy(), K, 255)
+    assert np.array_equal(ev.confusion(), conf_ref) and conf_ref.sum() == 3 * 97 * 131
+    res = ev.evaluate()["sem_seg"]
+    ref = madm_path.evaluator_metrics(conf_ref, K)
+    for k in ("mIoU", "fwIoU", "mACC", "pACC"):
+        assert res[k] == ref[k], k
+    assert all(res[f"IoU-{i}"] == 100 * ref["iou"][i] for i in range(K))
