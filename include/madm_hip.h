@@ -288,6 +288,21 @@ int madm_tanh_gate(const float* a1, const float* x1, const float* a2, const floa
  * evaluation/d2_evaluator.py:106. */
 int madm_argmax_nchw_f32(const float* x, int64_t* out, int B, int K, size_t HW, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Training-step tail on ONE flat, 16-byte-aligned fp32 buffer per role (HBM-bound).
+ * ------------------------------------------------------------------------------- */
+/* *out (f64, caller-zeroed) += sum x[i]^2 : the total norm of torch.nn.utils.clip_grad_norm_
+ * (engine/train_loop.py:203-217). */
+int madm_sumsq_f32(const float* x, size_t n, double* out, void* stream);
+/* torch.optim.AdamW step number `step` (>= 1) on p/g/m/v[n] (config_files/common/optim.py:8-17): the gradient is
+ * first multiplied by grad_scale = (1 / loss_scale) * min(1, clip / (norm + 1e-6)) -- GradScaler.unscale_ and
+ * clip_grad_norm_ folded into the same pass (28 bytes of HBM traffic per element instead of three passes). */
+int madm_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* ema = alpha * ema + (1 - alpha) * p : CMDISE._update_ema (modeling/meta_arch/cmdise.py:337-349), one launch for all
+ * teacher parameters instead of a Python loop over tensors. */
+int madm_ema_update(float* ema, const float* p, size_t n, float alpha, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,10 @@ SYMBOLS = [
                                c_int, c_int, c_void_p]),
     ("madm_tanh_gate", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     ("madm_argmax_nchw_f32", c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, c_void_p]),
+    ("madm_sumsq_f32", c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    ("madm_adamw_step", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_float,
+                                c_int, c_float, c_void_p]),
+    ("madm_ema_update", c_int, [c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     ("madm_nchw_f32_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 ]
 

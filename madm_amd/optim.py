@@ -1,0 +1,80 @@
+"""Flat-storage optimizer / EMA for the training-step tail.
+
+``FlatParams`` re-points every parameter of a module list at a slice of ONE contiguous fp32 buffer (and likewise the
+gradients), so the clip / AdamW / EMA passes are single launches over ~870 M elements instead of Python loops over
+~700 tensors (engine/train_loop.py:203-217, config_files/common/optim.py:8-17, modeling/meta_arch/cmdise.py:337-349).
+The forward-only modules of this package never allocate gradients; these classes are the device-side pieces a
+training loop needs once backward kernels exist."""
+import ctypes
+
+import torch
+
+from ._lib import lib, check
+from .ops import _stream, _need_cuda
+
+
+class FlatParams:
+    """Parameters of ``modules`` (in ``parameters()`` order, de-duplicated) as views into one flat fp32 buffer."""
+
+    def __init__(self, params, with_grad=True):
+        self.params = []
+        seen = set()
+        for p in params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
+        assert all(p.dtype == torch.float32 for p in self.params)
+        dev = self.params[0].device
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
+        self.numel = n
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev) if with_grad else None
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                view = self.flat[o:o + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                if with_grad:
+                    p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+
+def grad_sumsq(flat_grad):
+    _need_cuda(flat_grad)
+    out = torch.zeros(1, dtype=torch.float64, device=flat_grad.device)
+    check(lib.madm_sumsq_f32(flat_grad.data_ptr(), flat_grad.numel(), out.data_ptr(), _stream()), "madm_sumsq_f32")
+    return out
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics on a FlatParams (one parameter group), with the GradScaler unscale and the
+    clip_grad_norm_ coefficient folded into the update."""
+
+    def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.step_count = 0
+
+    def step(self, clip_grad=None, loss_scale=1.0):
+        """Returns the (unscaled) total gradient norm as a python float when clipping, else None."""
+        g = self.flat.grad
+        scale = 1.0 / loss_scale
+        norm = None
+        if clip_grad is not None:
+            norm = float(grad_sumsq(g).item()) ** 0.5 * scale      # one host sync, as clip_grad_norm_'s .item() users do
+            scale *= min(1.0, clip_grad / (norm + 1e-6))
+        self.step_count += 1
+        check(lib.madm_adamw_step(self.flat.flat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                  self.flat.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                  self.step_count, scale, _stream()), "madm_adamw_step")
+        return norm
+
+
+def ema_update(ema_flat, param_flat, alpha):
+    _need_cuda(ema_flat, param_flat)
+    assert ema_flat.numel() == param_flat.numel() and ema_flat.dtype == torch.float32
+    check(lib.madm_ema_update(ema_flat.data_ptr(), param_flat.data_ptr(), ema_flat.numel(), float(alpha), _stream()),
+          "madm_ema_update")

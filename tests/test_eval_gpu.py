@@ -246,3 +246,43 @@ def test_device_evaluator_is_bit_exact(cuda):
     for k in ("mIoU", "fwIoU", "mACC", "pACC"):
         assert res[k] == ref[k], k
     assert all(res[f"IoU-{i}"] == 100 * ref["iou"][i] for i in range(K))
+
+
+def test_flat_adamw_ema_clip(cuda):
+    """One-launch AdamW (+ folded unscale / clip) and EMA on flat fp32 storage against torch.optim.AdamW,
+    clip_grad_norm_ and the reference's EMA formula (cmdise.py:337-349) on CPU."""
+    import copy
+    from madm_amd.optim import FlatParams, FlatAdamW, ema_update, grad_sumsq
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Linear(53, 11))
+    ref = copy.deepcopy(net)
+    opt_ref = torch.optim.AdamW(ref.parameters(), lr=5e-3, weight_decay=0.05)
+    dev = copy.deepcopy(net).cuda()
+    flat = FlatParams(list(dev.parameters()))
+    opt = FlatAdamW(flat, lr=5e-3, weight_decay=0.05)
+    ema_ref = [p.detach().clone() for p in ref.parameters()]
+    ema_flat = flat.flat.clone()
+    for it in range(4):
+        grads = [torch.randn(p.shape, generator=torch.Generator().manual_seed(10 * it + i)) * (3.0 if it % 2 else 0.01)
+                 for i, p in enumerate(ref.parameters())]
+        loss_scale = 128.0
+        for p, pd, g in zip(ref.parameters(), dev.parameters(), grads):
+            p.grad = g.clone()
+            pd.grad.copy_((g * loss_scale).cuda())                 # scaled grads, as GradScaler leaves them
+        n_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5).item()
+        opt_ref.step()
+        n_dev = opt.step(clip_grad=0.5, loss_scale=loss_scale)
+        assert abs(n_dev - n_ref) / n_ref < 1e-5
+        alpha = min(1 - 1 / (it + 1), 0.999)
+        ema_ref = [alpha * e + (1 - alpha) * p.detach() for e, p in zip(ema_ref, ref.parameters())]
+        ema_update(ema_flat, flat.flat, alpha)
+    torch.cuda.synchronize()
+    for p, pd in zip(ref.parameters(), dev.parameters()):
+        assert rel_err(pd.detach().cpu(), p.detach())[0] < 2e-6
+    off = 0
+    for e, p in zip(ema_ref, dev.parameters()):
+        got = ema_flat[off:off + p.numel()].view_as(p).cpu()
+        assert rel_err(got, e)[0] < 2e-6
+        off += (p.numel() + 3) // 4 * 4
+    x = torch.randn(100003)
+    assert abs(grad_sumsq(x.cuda()[:100000].contiguous()).item() - (x[:100000].double() ** 2).sum().item()) < 1e-6 * 1e5
