@@ -96,10 +96,20 @@ def kernel_profile(model, inputs):
     finally:
         ops.PROFILE = None
     agg = {}
-    for name, flops, e0, e1, _ in rec:
-        n, ms, fl = agg.get(name, (0, 0.0, 0.0))
-        agg[name] = (n + 1, ms + e0.elapsed_time(e1), fl + flops)
+    for name, flops, e0, e1, _, nbytes in rec:
+        n, ms, fl, by = agg.get(name, (0, 0.0, 0.0, 0))
+        agg[name] = (n + 1, ms + e0.elapsed_time(e1), fl + flops, by + nbytes)
     return agg
+
+
+def pmc_traffic(kernel, workload):
+    """Mean HBM bytes per launch of ``kernel`` from the committed PMC passes of this same command
+    (tools/pmc.sh -> tools/pmc_report.py --json; counters cannot be read from inside the process)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_bench_{workload}.json")
+    try:
+        return json.load(open(path))["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def usable_cores():
@@ -249,10 +259,12 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
         }
         if prof:
             dom = max(prof.items(), key=lambda kv: kv[1][1])
-            name, (n, ms, fl) = dom
+            name, (n, ms, fl, by) = dom
             achieved = fl / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
-                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                               "traffic": pmc_traffic(name, args.workload),
+                               "algorithmic_bytes": by // n if by else None,
                                "launches_per_step": n, "kernel_ms_per_step": round(ms, 4)}
             out["kernels"] = {k: {"launches": v[0], "ms": round(v[1], 4),
                                   "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None}

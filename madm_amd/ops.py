@@ -76,8 +76,8 @@ def groupnorm_finalize(stats, B, HW, G, gamma, beta, eps):
 
 
 class _Prof:
-    def __init__(self, name, flops, desc=""):
-        self.name, self.flops, self.desc = name, flops, desc
+    def __init__(self, name, flops, desc="", nbytes=0):
+        self.name, self.flops, self.desc, self.nbytes = name, flops, desc, nbytes
 
     def __enter__(self):
         if PROFILE is not None:
@@ -89,7 +89,7 @@ class _Prof:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.name, self.flops, self.e0, self.e1, self.desc))
+            PROFILE.append((self.name, self.flops, self.e0, self.e1, self.desc, self.nbytes))
         return False
 
 
@@ -180,7 +180,11 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         name = _TILE_NAMES[lib.madm_conv2d_pick_tile(ctypes.byref(a))] + ("_f32" if x1.dtype == torch.float32 else "_bf16")
         desc = (f"M{M} N{N} K{KH * KW * (C1 + C2)} k{KH} s{stride}{' up' if upsample else ''}"
                 f"{' gn' if gn is not None else ''} sk{a.splitk}")
-        with _Prof(name, 2.0 * M * an * ak, desc):
+        es = x1.element_size()
+        # algorithmic HBM bytes: every input element, weight and output element once
+        nbytes = (B * IH * IW * (C1 + C2) * es + w.numel() * es
+                  + M * ocols * (4 if out_f32 else es) + (M * ocols * es if residual is not None else 0))
+        with _Prof(name, 2.0 * M * an * ak, desc, nbytes):
             check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     return out
 

@@ -1,24 +1,65 @@
 #!/usr/bin/env python3
-"""Aggregates rocprofv3 --pmc counter_collection CSVs (tools/pmc.sh) per kernel name."""
+"""Aggregates rocprofv3 --pmc counter_collection CSVs (tools/pmc.sh) per kernel name.
+
+  pmc_report.py <dir> [regex]            text view, mean counter value per dispatch
+  pmc_report.py <dir> --json out.json    HBM traffic per launch keyed by bench.py's kernel names
+                                         (FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reads half of the
+                                         streamed bytes -> x2, MI355X_MICROARCH.md "HBM / rocprofv3")"""
 import collections
 import csv
 import glob
+import json
 import re
 import sys
 
-d = sys.argv[1]
-pat = sys.argv[2] if len(sys.argv) > 2 else "."
-agg = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = re.sub(r"_ZN12_GLOBAL__N_1\d+", "", r["Kernel_Name"])[:60]
-        if not re.search(pat, k):
-            continue
-        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        cnt[k][r["Counter_Name"]] += 1
-for k, v in agg.items():
-    print(k)
-    for c, val in sorted(v.items()):
-        n = cnt[k][c]
-        print(f"   {c:28s} {val / n:16.1f} per dispatch ({n} dispatches)")
+
+def bench_name(k):
+    dt = lambda s: "_bf16" if s == "DF16b" else "_f32"
+    m = re.search(r"conv3x3_halo_kernelI(DF16b|f)Li(\d+)E", k)
+    if m:
+        return f"conv3x3_halo_x{m.group(2)}{dt(m.group(1))}"
+    m = re.search(r"igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)E", k)
+    if m:
+        return f"igemm_{m.group(2)}x{m.group(3)}{dt(m.group(1))}"
+    m = re.search(r"(splitk_reduce|gn_apply|gn_stats|layernorm|softmax_rows|image_to_im2col)_kernelI(DF16b|f)", k)
+    if m:
+        return m.group(1) + dt(m.group(2))
+    return None
+
+
+def main():
+    d = sys.argv[1]
+    as_json = len(sys.argv) > 3 and sys.argv[2] == "--json"
+    pat = "." if as_json or len(sys.argv) < 3 else sys.argv[2]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            k = bench_name(k) if as_json else re.sub(r"_ZN12_GLOBAL__N_1\d+", "", k)[:60]
+            if k is None or not re.search(pat, k):
+                continue
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k][r["Counter_Name"]] += 1
+    if as_json:
+        out = {}
+        for k, v in agg.items():
+            if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                fetch = 2.0 * 1024.0 * v["FETCH_SIZE"] / cnt[k]["FETCH_SIZE"]
+                write = 1024.0 * v["WRITE_SIZE"] / cnt[k]["WRITE_SIZE"]
+                out[k] = {"hbm_bytes_per_launch": round(fetch + write), "fetch_bytes_per_launch": round(fetch),
+                          "write_bytes_per_launch": round(write), "dispatches": cnt[k]["FETCH_SIZE"]}
+        json.dump({"source": "tools/pmc.sh (separate --pmc passes, --kernel-trace only); FETCH_SIZE KB x2 (gfx950), "
+                             "WRITE_SIZE KB; mean over the dispatches of each kernel in the traced run",
+                   "kernels": out}, open(sys.argv[3], "w"), indent=1)
+        print(json.dumps(out, indent=1))
+        return
+    for k, v in agg.items():
+        print(k)
+        for c, val in sorted(v.items()):
+            n = cnt[k][c]
+            print(f"   {c:28s} {val / n:16.1f} per dispatch ({n} dispatches)")
+
+
+if __name__ == "__main__":
+    main()
