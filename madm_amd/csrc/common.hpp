@@ -108,10 +108,23 @@ __device__ __forceinline__ void mma16<float>(const uint4& a, const uint4& b, f32
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, y.w, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x); v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE divide: this runs per staged element inside the
+// GroupNorm-fused conv, where the divide sequence alone cost more VALU issue than the tile's MFMAs
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // madm_act: 0 = none, 1 = SiLU, 2 = ReLU
 __device__ __forceinline__ float act_f(float x, int act) {
     return act == 1 ? silu_f(x) : (act == 2 ? fmaxf(x, 0.f) : x);
+}
+// the same over a register array with the (wave-uniform) selector tested once, not per element
+template <int N>
+__device__ __forceinline__ void act_inplace(float (&f)[N], int act) {
+    if (act == 1) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) f[j] = silu_f(f[j]);
+    } else if (act == 2) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) f[j] = fmaxf(f[j], 0.f);
+    }
 }
 __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));

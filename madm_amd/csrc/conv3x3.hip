@@ -22,10 +22,8 @@ __device__ __forceinline__ u32x4 gn_act_chunk(u32x4 raw, const float* sc, const 
     float f[EPC];
     chunk_to_f32<T>(__builtin_bit_cast(uint4, raw), f);
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) {
-        const float t = f[j] * sc[j] + sh[j];
-        f[j] = act_f(t, act);
-    }
+    for (int j = 0; j < EPC; ++j) f[j] = f[j] * sc[j] + sh[j];
+    act_inplace<EPC>(f, act);
     return __builtin_bit_cast(u32x4, f32_to_chunk<T>(f));
 }
 
@@ -207,38 +205,47 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const IgemmP p, int p
     // ---- epilogue (lane: pixel = patch row wm*4+i, column frow; channels n .. n+3) ----
     const bool want_stats = p.stats != nullptr && p.splitk == 1;
     float* red = reinterpret_cast<float*>(smem_raw);   // [2 (wm)][BN][2]
+    const int nb = n0 + wn * (BN / 2) + fg * 4;
+    f32x4 cs[NI], cq[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + fg * 4;
-        f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f}, cq = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int oy = py0 + wm * 4 + i, ox = px0 + frow;
-            if (oy < p.OH && ox < p.OW && n < p.N) {
-                const int m = (b * p.OH + oy) * p.OW + ox;
-                if (p.splitk > 1) {
-                    const f32x4 v = acc[i][j];
-                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n) =
+    for (int i = 0; i < MI; ++i) {
+        const int oy = py0 + wm * 4 + i, ox = px0 + frow;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        const int m = (b * p.OH + oy) * p.OW + ox;
+        if (p.splitk > 1) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const f32x4 v = acc[i][j];
+                if (nb + 16 * j < p.N)
+                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + nb + 16 * j) =
                         make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    const f32x4 v = epilogue_store<T>(p, m, n, acc[i][j]);
-                    if (want_stats) { cs += v; cq += v * v; }
-                }
+            }
+        } else {
+            epilogue_row<T, NI>(p, m, nb, acc[i]);
+            if (want_stats) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    if (nb + 16 * j < p.N) { cs[j] += acc[i][j]; cq[j] += acc[i][j] * acc[i][j]; }
             }
         }
-        if (want_stats) {
+    }
+    if (want_stats) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    cs[r] += __shfl_xor(cs[r], o);
-                    cq[r] += __shfl_xor(cq[r], o);
+                    cs[j][r] += __shfl_xor(cs[j][r], o);
+                    cq[j][r] += __shfl_xor(cq[j][r], o);
                 }
             }
             if (frow == 0) {
                 float* dst = red + ((wm * BN) + wn * (BN / 2) + j * 16 + fg * 4) * 2;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { dst[2 * r] = cs[r]; dst[2 * r + 1] = cq[r]; }
+                for (int r = 0; r < 4; ++r) { dst[2 * r] = cs[j][r]; dst[2 * r + 1] = cq[j][r]; }
             }
         }
     }

@@ -170,40 +170,49 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
     const int img0 = m0 / OHW;
     const bool one_image = (mlast / OHW) == img0;   // block-uniform
     float* red = reinterpret_cast<float*>(smem);     // [2 (wm)][BN][2], reuses the staging LDS
+    const int nb = n0 + wn * (BN / 2) + fg * 4;
+    f32x4 cs[NI], cq[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + fg * 4;
-        f32x4 cs = f32x4{0.f, 0.f, 0.f, 0.f}, cq = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + frow;
-            if (m < p.M && n < p.N) {
-                if (p.splitk > 1) {
-                    f32x4 v = acc[i][j];
-                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + n) =
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + frow;
+        if (m >= p.M) continue;
+        if (p.splitk > 1) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const f32x4 v = acc[i][j];
+                if (nb + 16 * j < p.N)
+                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + nb + 16 * j) =
                         make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    const f32x4 v = epilogue_store<T>(p, m, n, acc[i][j]);
-                    if (want_stats) {
-                        if (one_image) { cs += v; cq += v * v; }
-                        else stats_add_elementwise(p, m, n, v);
-                    }
+            }
+        } else {
+            epilogue_row<T, NI>(p, m, nb, acc[i]);
+            if (want_stats) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if (nb + 16 * j >= p.N) continue;
+                    if (one_image) { cs[j] += acc[i][j]; cq[j] += acc[i][j] * acc[i][j]; }
+                    else stats_add_elementwise(p, m, nb + 16 * j, acc[i][j]);
                 }
             }
         }
-        if (want_stats && one_image) {
+    }
+    if (want_stats && one_image) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    cs[r] += __shfl_xor(cs[r], o);
-                    cq[r] += __shfl_xor(cq[r], o);
+                    cs[j][r] += __shfl_xor(cs[j][r], o);
+                    cq[j][r] += __shfl_xor(cq[j][r], o);
                 }
             }
             if (frow == 0) {
                 float* dst = red + ((wm * BN) + wn * (BN / 2) + j * 16 + fg * 4) * 2;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { dst[2 * r] = cs[r]; dst[2 * r + 1] = cq[r]; }
+                for (int r = 0; r < 4; ++r) { dst[2 * r] = cs[j][r]; dst[2 * r + 1] = cq[j][r]; }
             }
         }
     }

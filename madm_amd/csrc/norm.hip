@@ -122,11 +122,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             chunk_to_f32<T>(rv, g);
         }
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) {
-            float t = f[j] * scale[q * EPC + j] + shift[q * EPC + j];
-            if (res) t += g[j];
-            f[j] = act_f(t, act);
+        for (int j = 0; j < EPC; ++j) f[j] = f[j] * scale[q * EPC + j] + shift[q * EPC + j];
+        if (res) {
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) f[j] += g[j];
         }
+        act_inplace<EPC>(f, act);
         *reinterpret_cast<uint4*>(yb + (size_t)r * ldy + q * EPC) = f32_to_chunk<T>(f);
     }
 }

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
             }
         }
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) acc[j] = act_f(acc[j] * scale[q * EPC + j] + shift[q * EPC + j], act);
+        for (int j = 0; j < EPC; ++j) acc[j] = acc[j] * scale[q * EPC + j] + shift[q * EPC + j];
+        act_inplace<EPC>(acc, act);
         *reinterpret_cast<uint4*>(y + (size_t)pix * ldy + q * EPC) = f32_to_chunk<T>(acc);
     }
 }

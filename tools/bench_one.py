@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--splitk", type=int, default=1)
     ap.add_argument("--gn", action="store_true")
+    ap.add_argument("--residual", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     args = ap.parse_args()
@@ -37,9 +38,10 @@ def main():
         gn = (torch.rand((B, Cin), device="cuda") + 0.5, torch.randn((B, Cin), device="cuda") * 0.1, True)
     st = torch.zeros((B, Cout, 2), dtype=torch.float64, device="cuda")
     lib.madm_debug_set_conv_tile(args.tile)
+    res = torch.randn((B * H * W, Cout), device="cuda").to(dtype) if args.residual else None
 
     def run():
-        return ops.conv2d(x, w, B, H, W, N=Cout, KH=k, KW=k, pad_t=k // 2, pad_l=k // 2, bias=bias, stats=st, gn=gn,
+        return ops.conv2d(x, w, B, H, W, N=Cout, KH=k, KW=k, pad_t=k // 2, pad_l=k // 2, bias=bias, stats=st, gn=gn, residual=res,
                           splitk=args.splitk)
 
     for _ in range(3):
