@@ -127,7 +127,7 @@ int madm_conv2d_can_fuse_groupnorm(const madm_conv2d_args* a);
  * (used by bench.py to attribute time). */
 int madm_conv2d_pick_tile(const madm_conv2d_args* a);
 /* tuning/debug aid: force the workgroup tile (0 = tuned table then heuristic, -1 = heuristic only,
- * 1..5 = the tile codes of madm_conv2d_pick_tile). */
+ * 1..6 = the tile codes of madm_conv2d_pick_tile). */
 void madm_debug_set_conv_tile(int tile);
 
 /* ---------------------------------------------------------------------------------

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
     }
 }
 
-int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..5 = forced tile code
+int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
+inline bool is_igemm_tile(int t) { return t <= 3 || t == 6; }
 
 // Launch configurations measured on MI355X by tools/tune_conv.py for the layer shapes of the SD-v1-4
 // feature extractor at bs=2, 512x512 (any other shape falls back to the heuristics below).
@@ -311,7 +312,8 @@ bool halo_eligible(const madm_conv2d_args* a) {
            a->OH == a->IH && a->OW == a->IW && a->OH >= 8 && a->OW >= 16 && a->epilogue != MADM_EPI_GEGLU;
 }
 
-// tile codes: 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 BN=128, 5 = halo BN=64
+// tile codes: 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 BN=128, 5 = halo BN=64,
+// 6 = igemm 64x64 with an 8-deep register prefetch (latency-bound small-M GEMMs streaming cold weights)
 int pick_tile(const madm_conv2d_args* a) {
     const int M = a->B * a->OH * a->OW, K = a->KH * a->KW * (a->C1 + a->C2);
     const bool halo_ok = halo_eligible(a);
@@ -319,12 +321,12 @@ int pick_tile(const madm_conv2d_args* a) {
     if (a->gn_scale) {   // fused GroupNorm exists only in the halo kernel
         if (g_tile_override == 4 || g_tile_override == 5) return g_tile_override;
         if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH))
-            if (t->tile >= 4) return t->tile;
+            if (t->tile == 4 || t->tile == 5) return t->tile;
         return halo_default;
     }
-    if (g_tile_override > 0 && (g_tile_override <= 3 || halo_ok)) return g_tile_override;
+    if (g_tile_override > 0 && (is_igemm_tile(g_tile_override) || halo_ok)) return g_tile_override;
     if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH))
-        if (t->tile <= 3 || halo_ok) return t->tile;
+        if (is_igemm_tile(t->tile) || halo_ok) return t->tile;
     if (halo_ok && M >= 2048) return halo_default;
     return heuristic_tile(M, a->N);
 }
@@ -394,7 +396,7 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
     int bm, bn;
     tile_dims(t, bm, bn);
     int rc;
-    if (t >= 4) {
+    if (t == 4 || t == 5) {
         rc = launch_conv3x3_halo<T>(p, bn, s);
     } else {
         p.tilesN = (p.N + bn - 1) / bn;
@@ -402,6 +404,7 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
         dim3 grid((unsigned)(tilesM * p.tilesN), 1, (unsigned)p.splitk);
         if (t == 1) igemm_kernel<T, 128, 128, 2><<<grid, 256, 0, s>>>(p);
         else if (t == 2) igemm_kernel<T, 128, 64, 3><<<grid, 256, 0, s>>>(p);
+        else if (t == 6) igemm_kernel<T, 64, 64, 8><<<grid, 256, 0, s>>>(p);
         else igemm_kernel<T, 64, 64, 4><<<grid, 256, 0, s>>>(p);
         rc = madm_check_launch("igemm_kernel");
     }

@@ -18,9 +18,10 @@ __device__ __forceinline__ void block_minmax(float lo, float hi, float* minmax) 
     if (threadIdx.x == 0) {
         const int nw = (blockDim.x + 63) >> 6;
         for (int i = 1; i < nw; ++i) { lo = fminf(lo, s_lo[i]); hi = fmaxf(hi, s_hi[i]); }
+        // min / max only move one way: a block that cannot improve the published bound skips its atomic
         if (lo <= hi) {
-            atomicMin(&minmax[0], lo);
-            atomicMax(&minmax[1], hi);
+            if (lo < __builtin_nontemporal_load(&minmax[0])) atomicMin(&minmax[0], lo);
+            if (hi > __builtin_nontemporal_load(&minmax[1])) atomicMax(&minmax[1], hi);
         }
     }
 }
@@ -58,44 +59,48 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
 
 // NCHW f32 3-channel image -> im2col rows of the 3x3/pad-1 stem conv: out[pixel][k], k = (r*3+s)*3 + c
 // holding (img[c, y+r-1, x+s-1] - mean) / std (zero outside the image: the conv pads the NORMALISED
-// image), k >= 27 zero.  One thread per (pixel, 16-byte chunk): coalesced 16-byte stores.
+// image), k >= 27 zero.  One block per 64-pixel row segment: the 3 planes x 3 rows x 66 normalised inputs go
+// through LDS (coalesced row reads), then every thread assembles 16-byte chunks and consecutive threads write
+// consecutive 16 bytes -- the kernel is bound by the Kpad * sizeof(T) bytes it writes per pixel.
+constexpr int IM2COL_PX = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void image_to_im2col_kernel(const float* __restrict__ img, T* __restrict__ out,
                                                               int B, int H, int W, int Kpad, float mean,
                                                               float inv_std, float* minmax) {
-    // one thread per pixel: 27 (L1/L2-resident) neighbour reads, one full Kpad*sizeof(T)-byte row written
     constexpr int EPC = TT<T>::EPC;
-    const unsigned HW = (unsigned)H * W;
-    const unsigned total = (unsigned)B * HW;
+    constexpr int TW = IM2COL_PX + 2;
+    __shared__ float tile[9 * TW];   // [c][r][x]
+    const unsigned segs = (unsigned)(W + IM2COL_PX - 1) / IM2COL_PX;
+    const unsigned seg = blockIdx.x % segs, row = blockIdx.x / segs;   // row = b * H + y
+    const int b = (int)(row / (unsigned)H), y = (int)(row - (unsigned)b * H), x0 = (int)seg * IM2COL_PX;
+    const size_t HW = (size_t)H * W;
+    const float* ib = img + (size_t)b * 3 * HW;
     float lo = INFINITY, hi = -INFINITY;
-    for (unsigned pix = blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += gridDim.x * blockDim.x) {
-        const unsigned b = pix / HW;
-        const unsigned rem = pix - b * HW;
-        const int y = (int)(rem / (unsigned)W), x = (int)(rem - (rem / (unsigned)W) * (unsigned)W);
-        const float* ib = img + (size_t)b * 3 * HW;
-        float v[32];
+    for (int i = threadIdx.x; i < 9 * TW; i += 256) {
+        const int cr = i / TW, xx = i - cr * TW;
+        const int c = cr / 3, r = cr - 3 * c;
+        const int yy = y + r - 1, gx = x0 + xx - 1;
+        float t = 0.f;
+        if ((unsigned)yy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+            t = (ib[(size_t)c * HW + (size_t)yy * W + gx] - mean) * inv_std;
+            if (r == 1 && xx >= 1 && xx <= IM2COL_PX) { lo = fminf(lo, t); hi = fmaxf(hi, t); }   // the segment itself
+        }
+        tile[i] = t;
+    }
+    __syncthreads();
+    const int CPR = Kpad / EPC;
+    for (int i = threadIdx.x; i < IM2COL_PX * CPR; i += 256) {
+        const int p = i / CPR, q = i - p * CPR;
+        if (x0 + p >= W) break;
+        float v[EPC];
 #pragma unroll
-        for (int k = 27; k < 32; ++k) v[k] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int s2 = 0; s2 < 3; ++s2) {
-                const int yy = y + r - 1, xx = x + s2 - 1;
-                const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float t = 0.f;
-                    if (ok) t = (ib[(unsigned)c * HW + (unsigned)yy * W + xx] - mean) * inv_std;
-                    v[(r * 3 + s2) * 3 + c] = t;
-                }
-            }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { lo = fminf(lo, v[12 + c]); hi = fmaxf(hi, v[12 + c]); }
-        T* o = out + (size_t)pix * Kpad;
-#pragma unroll
-        for (int q = 0; q < 32 / EPC; ++q) *reinterpret_cast<uint4*>(o + q * EPC) = f32_to_chunk<T>(v + q * EPC);
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        for (int q = 32 / EPC; q < Kpad / EPC; ++q) *reinterpret_cast<uint4*>(o + q * EPC) = z;
+        for (int j = 0; j < EPC; ++j) {
+            const int k = q * EPC + j;          // k = (r * 3 + s) * 3 + c
+            const int tap = k / 3, c = k - 3 * tap;
+            const int r = tap / 3, s2 = tap - 3 * r;
+            v[j] = (k < 27) ? tile[(c * 3 + r) * TW + p + s2] : 0.f;
+        }
+        *reinterpret_cast<uint4*>(out + ((size_t)row * W + x0 + p) * Kpad + q * EPC) = f32_to_chunk<T>(v);
     }
     if (minmax) block_minmax(lo, hi, minmax);
 }
@@ -242,7 +247,7 @@ int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H
     MADM_REQUIRE(Kpad >= 32, "image_to_im2col3x3: Kpad must be at least 32");
     const size_t total = (size_t)B * H * W;
     MADM_REQUIRE(total * Kpad < 0x7fffffffull, "image_to_im2col3x3: tensor too large for 32-bit indexing");
-    MADM_DISPATCH_DTYPE(dtype, (image_to_im2col_kernel<T><<<grid_for(total, 2048), 256, 0, s>>>(
+    MADM_DISPATCH_DTYPE(dtype, (image_to_im2col_kernel<T><<<(unsigned)((size_t)B * H * ((W + IM2COL_PX - 1) / IM2COL_PX)), 256, 0, s>>>(
                                    img, (T*)out, B, H, W, Kpad, mean, 1.0f / std, minmax)));
     return madm_check_launch("image_to_im2col_kernel");
 }

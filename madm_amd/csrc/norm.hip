@@ -72,13 +72,58 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int cpg = Ctot / G;
     const double cnt = (double)HW * (double)cpg;
     const int C2 = Ctot - C1;
-    // group fold: 8 lanes per group, each summing every 8th channel of the group (independent loads),
-    // then an xor-shuffle reduction -- a serial per-group loop here would cost cpg dependent HBM/L2 latencies
+    const unsigned CPR = (unsigned)C / EPC;
+    const unsigned total = (unsigned)HW * CPR;   // < 2^31 (checked by the launcher)
+    const T* xb = x + (size_t)b * HW * C;
+    T* yb = y + (size_t)b * HW * ldy + c_off;
+    const unsigned idx0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+
+    // Everything this block needs from memory is requested up front -- the first PF row chunks (and residuals), the
+    // affine parameters, the channel sums -- so the three dependent L2/HBM round trips of the naive order
+    // (sums -> gamma/beta -> x) overlap; on the UNet's small tensors this kernel is pure latency.
+    constexpr int PF = 4;
+    uint4 xv[PF], rv[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const unsigned idx = idx0 + k * stride;
+        xv[k] = make_uint4(0, 0, 0, 0);
+        rv[k] = make_uint4(0, 0, 0, 0);
+        if (idx < total) {
+            xv[k] = *reinterpret_cast<const uint4*>(xb + (size_t)idx * EPC);
+            if (res) {
+                const unsigned r = idx / CPR, q = idx - r * CPR;
+                rv[k] = *reinterpret_cast<const uint4*>(res + ((size_t)b * HW + r) * ldres + c_off + q * EPC);
+            }
+        }
+    }
+    gamma += c_off;
+    beta += c_off;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {   // raw gamma / beta; turned into scale / shift below
+        scale[c] = gamma[c];
+        shift[c] = beta[c];
+    }
+    // group fold: 8 lanes per group, each summing every 8th channel of the group with all its loads in flight
+    // together, then an xor-shuffle reduction
     for (int g0 = 0; g0 < G; g0 += 32) {
         const int g = g0 + (threadIdx.x >> 3), l = threadIdx.x & 7;
         double s = 0.0, q = 0.0;
         if (g < G) {
-            for (int ch = g * cpg + l; ch < (g + 1) * cpg; ch += 8) {
+            constexpr int UF = 10;   // covers C <= 2560 at 32 groups without a dependent loop
+            double sv[UF], qv[UF];
+#pragma unroll
+            for (int i = 0; i < UF; ++i) {
+                const int ch = g * cpg + l + 8 * i;
+                sv[i] = 0.0;
+                qv[i] = 0.0;
+                if (ch < (g + 1) * cpg) {
+                    const double* src = (ch < C1) ? sums1 + ((size_t)b * C1 + ch) * 2 : sums2 + ((size_t)b * C2 + (ch - C1)) * 2;
+                    sv[i] = src[0];
+                    qv[i] = src[1];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < UF; ++i) { s += sv[i]; q += qv[i]; }
+            for (int ch = g * cpg + l + 8 * UF; ch < (g + 1) * cpg; ch += 8) {
                 const double* src = (ch < C1) ? sums1 + ((size_t)b * C1 + ch) * 2 : sums2 + ((size_t)b * C2 + (ch - C1)) * 2;
                 s += src[0];
                 q += src[1];
@@ -98,37 +143,42 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         }
     }
     __syncthreads();
-    gamma += c_off;
-    beta += c_off;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int g = (c_off + c) / cpg;
-        const float sc = grstd[g] * gamma[c];
+        const float sc = grstd[g] * scale[c];
         scale[c] = sc;
-        shift[c] = beta[c] - gmean[g] * sc;
+        shift[c] = shift[c] - gmean[g] * sc;
     }
     __syncthreads();
-    const unsigned CPR = (unsigned)C / EPC;
-    const unsigned total = (unsigned)HW * CPR;   // < 2^31 (checked by the launcher)
-    const T* xb = x + (size_t)b * HW * C;
-    T* yb = y + (size_t)b * HW * ldy + c_off;
-    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+
+    auto emit = [&](unsigned idx, uint4 v, uint4 rvv) {
         const unsigned r = idx / CPR;
         const unsigned q = idx - r * CPR;
-        uint4 v = *reinterpret_cast<const uint4*>(xb + (size_t)idx * EPC);
         float f[EPC], g[EPC];
         chunk_to_f32<T>(v, f);
-        if (res) {
-            const uint4 rv = *reinterpret_cast<const uint4*>(res + ((size_t)b * HW + r) * ldres + c_off + q * EPC);
-            chunk_to_f32<T>(rv, g);
-        }
 #pragma unroll
         for (int j = 0; j < EPC; ++j) f[j] = f[j] * scale[q * EPC + j] + shift[q * EPC + j];
         if (res) {
+            chunk_to_f32<T>(rvv, g);
 #pragma unroll
             for (int j = 0; j < EPC; ++j) f[j] += g[j];
         }
         act_inplace<EPC>(f, act);
         *reinterpret_cast<uint4*>(yb + (size_t)r * ldy + q * EPC) = f32_to_chunk<T>(f);
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const unsigned idx = idx0 + k * stride;
+        if (idx < total) emit(idx, xv[k], rv[k]);
+    }
+    for (unsigned idx = idx0 + PF * stride; idx < total; idx += stride) {
+        const uint4 v = *reinterpret_cast<const uint4*>(xb + (size_t)idx * EPC);
+        uint4 rvv = make_uint4(0, 0, 0, 0);
+        if (res) {
+            const unsigned r = idx / CPR, q = idx - r * CPR;
+            rvv = *reinterpret_cast<const uint4*>(res + ((size_t)b * HW + r) * ldres + c_off + q * EPC);
+        }
+        emit(idx, v, rvv);
     }
 }
 
@@ -329,7 +379,7 @@ int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int 
     MADM_REQUIRE(shm <= 64 * 1024, "groupnorm_apply: C=%d too large", C);
     const size_t total = (size_t)HW * (C / epc);
     MADM_REQUIRE(total < 0x7fffffffull, "groupnorm_apply: tensor too large for 32-bit indexing");
-    size_t strips = (total + 256 * 8 - 1) / (256 * 8);
+    size_t strips = (total + 256 * 4 - 1) / (256 * 4);   // <= 4 chunks per thread: all of them prefetched
     const size_t maxstrips = (size_t)(2048 + B - 1) / B;
     if (strips > maxstrips) strips = maxstrips;
     if (strips < 1) strips = 1;

@@ -47,7 +47,9 @@ _workspaces = {}
 # appends (kernel name, algorithmic FLOPs, start event, end event) recorded on the launch stream.
 PROFILE = None
 CAPTURE = None   # tools/tune_conv.py: when a list, conv2d appends (args struct, tensors kept alive, desc)
-_TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64", 4: "conv3x3_halo_x128", 5: "conv3x3_halo_x64"}
+_TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64", 4: "conv3x3_halo_x128", 5: "conv3x3_halo_x64",
+               6: "igemm_64x64d"}
+FORCE_SPLITK = None   # tools/tune_insitu.py: split-K factor forced on every small-M launch
 FUSE_GN = True   # fold GroupNorm(+SiLU) into eligible 3x3 convs (debug switch)
 import os as _os
 FUSE_GN_MAX_N = int(_os.environ.get("MADM_FUSE_GN_MAX_N", "128"))   # ... whose output fits one 128-channel tile
@@ -160,6 +162,9 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         assert gs.numel() == B * (C1 + C2) and gh.numel() == gs.numel()
         a.gn_scale, a.gn_shift, a.gn_act = gs.data_ptr(), gh.data_ptr(), _act_code(act=act)
     a.splitk = 1
+    if FORCE_SPLITK is not None and splitk is None:
+        nk = KH * KW * (C1 + C2) // k_tile(x1.dtype)
+        splitk = FORCE_SPLITK if (M <= 16384 and FORCE_SPLITK <= max(1, nk // 2)) else 1
     if splitk is None:
         splitk = lib.madm_conv2d_suggest_splitk(ctypes.byref(a))
     a.splitk = max(1, int(splitk))

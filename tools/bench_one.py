@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--splitk", type=int, default=1)
     ap.add_argument("--gn", action="store_true")
     ap.add_argument("--residual", action="store_true")
+    ap.add_argument("--rotate", type=int, default=1, help="cycle through this many weight buffers (cold weights, as in the model)")
+    ap.add_argument("--no-stats", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     args = ap.parse_args()
@@ -31,16 +33,19 @@ def main():
     H, W = args.hw
     B, Cin, Cout, k = args.B, args.cin, args.cout, args.k
     x = torch.randn((B * H * W, Cin), device="cuda").to(dtype)
-    w = (torch.randn((Cout, k * k * Cin), device="cuda") / math.sqrt(k * k * Cin)).to(dtype)
+    ws = [(torch.randn((Cout, k * k * Cin), device="cuda") / math.sqrt(k * k * Cin)).to(dtype) for _ in range(args.rotate)]
+    it = [0]
     bias = torch.randn(Cout, device="cuda")
     gn = None
     if args.gn:
         gn = (torch.rand((B, Cin), device="cuda") + 0.5, torch.randn((B, Cin), device="cuda") * 0.1, True)
-    st = torch.zeros((B, Cout, 2), dtype=torch.float64, device="cuda")
+    st = None if args.no_stats else torch.zeros((B, Cout, 2), dtype=torch.float64, device="cuda")
     lib.madm_debug_set_conv_tile(args.tile)
     res = torch.randn((B * H * W, Cout), device="cuda").to(dtype) if args.residual else None
 
     def run():
+        it[0] += 1
+        w = ws[it[0] % len(ws)]
         return ops.conv2d(x, w, B, H, W, N=Cout, KH=k, KW=k, pad_t=k // 2, pad_l=k // 2, bias=bias, stats=st, gn=gn, residual=res,
                           splitk=args.splitk)
 
@@ -55,7 +60,7 @@ def main():
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / args.reps * 1e3
     fl = 2.0 * B * H * W * Cout * k * k * Cin
-    print(f"tile {args.tile} M{B * H * W} N{Cout} K{k * k * Cin}: {us:.1f} us  {fl / us / 1e6:.1f} TF/s")
+    print(f"tile {args.tile} sk{args.splitk} rot{args.rotate} M{B * H * W} N{Cout} K{k * k * Cin}: {us:.1f} us  {fl / us / 1e6:.1f} TF/s")
 
 
 if __name__ == "__main__":
