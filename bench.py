@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--graphs", type=int, default=1,
+                    help="graph executables replayed round-robin (measured: 1, 2 and 3 give the same step time, the "
+                         "host-side launch of a replay already overlaps the previous one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lora", action="store_true", help="enable one r=8 LoRA adapter (north_star variant)")
@@ -202,19 +205,25 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
         def step():
             return model(*call)
     else:
-        graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             model(*call)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with torch.cuda.graph(graph):
-            static_out = model(*call)
+        graphs, outs = [], []
+        for _ in range(max(1, args.graphs)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs.append(model(*call))
+            graphs.append(g)
+        turn = [0]
 
         def step():
-            graph.replay()
-            return static_out
+            i = turn[0] % len(graphs)
+            turn[0] += 1
+            graphs[i].replay()
+            return outs[i]
 
     for _ in range(args.warmup):
         step()

@@ -28,7 +28,7 @@ __device__ __forceinline__ u32x4 gn_act_chunk(u32x4 raw, const float* sc, const 
 }
 
 template <typename T, int BN, bool FUSE>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;
     constexpr int MI = 4, NI = BN / 32;     // wave tile: 4 patch rows (64 px) x BN/2 channels

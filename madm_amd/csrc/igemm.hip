@@ -13,7 +13,7 @@
 namespace {
 
 template <typename T, int BM, int BN, int NST>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmP p) {
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_kernel(const IgemmP p) {
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;            // elements per K tile (128 B per row)
     constexpr int RA = BM / 32, RB = BN / 32;  // rows staged per thread
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
 int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
 inline bool is_igemm_tile(int t) { return t <= 3 || t == 6; }
 
-// Launch configurations measured on MI355X by tools/tune_conv.py for the layer shapes of the SD-v1-4
+// Launch configurations measured on MI355X by tools/tune_insitu.py for the layer shapes of the SD-v1-4
 // feature extractor at bs=2, 512x512 (any other shape falls back to the heuristics below).
 struct Tuned { int dtype, M, N, K, KH, tile, splitk; };
 const Tuned g_tuned[] = {

@@ -18,22 +18,53 @@ __device__ __forceinline__ void block_minmax(float lo, float hi, float* minmax) 
     if (threadIdx.x == 0) {
         const int nw = (blockDim.x + 63) >> 6;
         for (int i = 1; i < nw; ++i) { lo = fminf(lo, s_lo[i]); hi = fmaxf(hi, s_hi[i]); }
-        // min / max only move one way: a block that cannot improve the published bound skips its atomic
+        // Native integer atomics on the float bit patterns (sign-aware: for v >= 0 the signed-int order is the float
+        // order, for v < 0 the unsigned order is the reversed float order).  atomicMin/Max(float*) compile to CAS
+        // loops: with the first ~2000 resident blocks all improving the freshly reset bound they serialised into
+        // ~0.5 ms per call.  A block that cannot improve the published bound skips its atomic altogether.
         if (lo <= hi) {
-            if (lo < __builtin_nontemporal_load(&minmax[0])) atomicMin(&minmax[0], lo);
-            if (hi > __builtin_nontemporal_load(&minmax[1])) atomicMax(&minmax[1], hi);
+            if (lo < __builtin_nontemporal_load(&minmax[0])) {
+                if (lo >= 0.f) atomicMin(reinterpret_cast<int*>(&minmax[0]), __float_as_int(lo));
+                else atomicMax(reinterpret_cast<unsigned*>(&minmax[0]), __float_as_uint(lo));
+            }
+            if (hi > __builtin_nontemporal_load(&minmax[1])) {
+                if (hi >= 0.f) atomicMax(reinterpret_cast<int*>(&minmax[1]), __float_as_int(hi));
+                else atomicMin(reinterpret_cast<unsigned*>(&minmax[1]), __float_as_uint(hi));
+            }
         }
     }
+}
+
+// min / max of (x - mean) * inv_std over a flat f32 buffer, folded into minmax[2] (the reference's input-range
+// assert, ldm_diffusers.py:147).  A FEW blocks only: agent-scope atomics on one address execute at the memory side
+// at ~85 ns each, so one atomic pair per block of the image kernels (8192 blocks) cost 0.5-0.7 ms per call --
+// far more than the transform itself; 64 blocks re-read the (L2/MALL-resident) image instead.
+__global__ __launch_bounds__(256) void range_probe_kernel(const float* __restrict__ x, size_t n, float mean,
+                                                          float inv_std, float* minmax) {
+    float lo = INFINITY, hi = -INFINITY;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float a = (v.x - mean) * inv_std, b = (v.y - mean) * inv_std, c = (v.z - mean) * inv_std,
+                    d = (v.w - mean) * inv_std;
+        lo = fminf(fminf(lo, a), fminf(fminf(b, c), d));
+        hi = fmaxf(fmaxf(hi, a), fmaxf(fmaxf(b, c), d));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float a = (x[n4 * 4 + threadIdx.x] - mean) * inv_std;
+        lo = fminf(lo, a);
+        hi = fmaxf(hi, a);
+    }
+    block_minmax(lo, hi, minmax);
 }
 
 // NCHW f32 image -> channels-last dtype, (x - mean) / std in the first C channels, zeros above.
 template <typename T>
 __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restrict__ img, T* __restrict__ out,
                                                             int B, int C, int HW, int Cpad, float mean,
-                                                            float inv_std, float* minmax) {
+                                                            float inv_std) {
     constexpr int EPC = TT<T>::EPC;
     const unsigned total = (unsigned)B * (unsigned)HW;
-    float lo = INFINITY, hi = -INFINITY;
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int b = (int)(idx / (unsigned)HW);
         const int px = (int)(idx - (unsigned)b * (unsigned)HW);
@@ -44,17 +75,12 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
             for (int j = 0; j < EPC; ++j) {
                 const int c = q * EPC + j;
                 float v = 0.f;
-                if (c < C) {
-                    v = (img[((size_t)b * C + c) * HW + px] - mean) * inv_std;
-                    lo = fminf(lo, v);
-                    hi = fmaxf(hi, v);
-                }
+                if (c < C) v = (img[((size_t)b * C + c) * HW + px] - mean) * inv_std;
                 f[j] = v;
             }
             *reinterpret_cast<uint4*>(o + q * EPC) = f32_to_chunk<T>(f);
         }
     }
-    if (minmax) block_minmax(lo, hi, minmax);
 }
 
 // NCHW f32 3-channel image -> im2col rows of the 3x3/pad-1 stem conv: out[pixel][k], k = (r*3+s)*3 + c
@@ -66,7 +92,7 @@ constexpr int IM2COL_PX = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void image_to_im2col_kernel(const float* __restrict__ img, T* __restrict__ out,
                                                               int B, int H, int W, int Kpad, float mean,
-                                                              float inv_std, float* minmax) {
+                                                              float inv_std) {
     constexpr int EPC = TT<T>::EPC;
     constexpr int TW = IM2COL_PX + 2;
     __shared__ float tile[9 * TW];   // [c][r][x]
@@ -75,16 +101,13 @@ __global__ __launch_bounds__(256) void image_to_im2col_kernel(const float* __res
     const int b = (int)(row / (unsigned)H), y = (int)(row - (unsigned)b * H), x0 = (int)seg * IM2COL_PX;
     const size_t HW = (size_t)H * W;
     const float* ib = img + (size_t)b * 3 * HW;
-    float lo = INFINITY, hi = -INFINITY;
     for (int i = threadIdx.x; i < 9 * TW; i += 256) {
         const int cr = i / TW, xx = i - cr * TW;
         const int c = cr / 3, r = cr - 3 * c;
         const int yy = y + r - 1, gx = x0 + xx - 1;
         float t = 0.f;
-        if ((unsigned)yy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+        if ((unsigned)yy < (unsigned)H && (unsigned)gx < (unsigned)W)
             t = (ib[(size_t)c * HW + (size_t)yy * W + gx] - mean) * inv_std;
-            if (r == 1 && xx >= 1 && xx <= IM2COL_PX) { lo = fminf(lo, t); hi = fmaxf(hi, t); }   // the segment itself
-        }
         tile[i] = t;
     }
     __syncthreads();
@@ -102,7 +125,6 @@ __global__ __launch_bounds__(256) void image_to_im2col_kernel(const float* __res
         }
         *reinterpret_cast<uint4*>(out + ((size_t)row * W + x0 + p) * Kpad + q * EPC) = f32_to_chunk<T>(v);
     }
-    if (minmax) block_minmax(lo, hi, minmax);
 }
 
 template <typename T>
@@ -219,6 +241,16 @@ unsigned grid_for(size_t n, unsigned cap = 2048) {
     return (unsigned)g;
 }
 
+int launch_range_probe(const float* img, size_t n, float mean, float inv_std, float* minmax, hipStream_t s) {
+    if (!minmax) return MADM_OK;
+    MADM_REQUIRE((reinterpret_cast<uintptr_t>(img) & 15) == 0, "image range probe: image must be 16-byte aligned");
+    size_t blocks = (n / 4 + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 64) blocks = 64;
+    if (blocks < 1) blocks = 1;
+    range_probe_kernel<<<(unsigned)blocks, 256, 0, s>>>(img, n, mean, inv_std, minmax);
+    return madm_check_launch("range_probe_kernel");
+}
+
 }  // namespace
 
 extern "C" {
@@ -233,8 +265,9 @@ int madm_image_to_nhwc(int dtype, const float* img, void* out, int B, int C, int
     hipStream_t s = (hipStream_t)stream;
     const size_t total = (size_t)B * H * W;
     MADM_DISPATCH_DTYPE(dtype, (image_to_nhwc_kernel<T><<<grid_for(total), 256, 0, s>>>(
-                                   img, (T*)out, B, C, H * W, Cpad, mean, 1.0f / std, minmax)));
-    return madm_check_launch("image_to_nhwc_kernel");
+                                   img, (T*)out, B, C, H * W, Cpad, mean, 1.0f / std)));
+    if (int rc = madm_check_launch("image_to_nhwc_kernel")) return rc;
+    return launch_range_probe(img, (size_t)B * C * H * W, mean, 1.0f / std, minmax, s);
 }
 
 int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H, int W, int Kpad, float mean,
@@ -248,8 +281,9 @@ int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H
     const size_t total = (size_t)B * H * W;
     MADM_REQUIRE(total * Kpad < 0x7fffffffull, "image_to_im2col3x3: tensor too large for 32-bit indexing");
     MADM_DISPATCH_DTYPE(dtype, (image_to_im2col_kernel<T><<<(unsigned)((size_t)B * H * ((W + IM2COL_PX - 1) / IM2COL_PX)), 256, 0, s>>>(
-                                   img, (T*)out, B, H, W, Kpad, mean, 1.0f / std, minmax)));
-    return madm_check_launch("image_to_im2col_kernel");
+                                   img, (T*)out, B, H, W, Kpad, mean, 1.0f / std)));
+    if (int rc = madm_check_launch("image_to_im2col_kernel")) return rc;
+    return launch_range_probe(img, (size_t)B * 3 * H * W, mean, 1.0f / std, minmax, s);
 }
 
 int madm_nchw_f32_to_nhwc(int dtype, const float* x, void* out, int B, int C, int HW, int Cpad, void* stream) {

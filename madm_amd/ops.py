@@ -46,7 +46,6 @@ _workspaces = {}
 # Optional per-launch profiler used by bench.py: when PROFILE is a list, every MFMA-kernel launch
 # appends (kernel name, algorithmic FLOPs, start event, end event) recorded on the launch stream.
 PROFILE = None
-CAPTURE = None   # tools/tune_conv.py: when a list, conv2d appends (args struct, tensors kept alive, desc)
 _TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64", 4: "conv3x3_halo_x128", 5: "conv3x3_halo_x64",
                6: "igemm_64x64d"}
 FORCE_SPLITK = None   # tools/tune_insitu.py: split-K factor forced on every small-M launch
@@ -174,10 +173,6 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         ws = _workspace(nbytes, x1.device)
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
-    if CAPTURE is not None:
-        CAPTURE.append((a, (x1, x2, w, bias, rowvec, residual, out, stats, ws, gn),
-                        f"M{M} N{N} K{KH * KW * (C1 + C2)} k{KH} s{stride}{' up' if upsample else ''}"
-                        f"{' cat' if C2 else ''}{' st' if stats is not None else ''}{' gn' if gn is not None else ''}"))
     if PROFILE is None:
         check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     else:
