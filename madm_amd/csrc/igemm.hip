@@ -286,15 +286,17 @@ inline bool is_igemm_tile(int t) { return t <= 3 || t == 6; }
 
 // Launch configurations measured on MI355X by tools/tune_insitu.py for the layer shapes of the SD-v1-4
 // feature extractor at bs=2, 512x512 (any other shape falls back to the heuristics below).
-struct Tuned { int dtype, M, N, K, KH, tile, splitk; };
+// variant: 0 = plain, 1 = GroupNorm fused into the halo load, 2 = nearest-2x upsample gather
+struct Tuned { int dtype, M, N, K, KH, variant, tile, splitk; };
+inline int variant_of(const madm_conv2d_args* a) { return a->gn_scale ? 1 : (a->upsample ? 2 : 0); }
 const Tuned g_tuned[] = {
 #include "igemm_tuned.inc"
-    {-1, 0, 0, 0, 0, 0, 0}};
+    {-1, 0, 0, 0, 0, 0, 0, 0}};
 
-const Tuned* find_tuned(int dtype, int M, int N, int K, int KH) {
+const Tuned* find_tuned(int dtype, int M, int N, int K, int KH, int variant) {
     if (g_tile_override != 0) return nullptr;
     for (const Tuned* t = g_tuned; t->dtype >= 0; ++t)
-        if (t->dtype == dtype && t->M == M && t->N == N && t->K == K && t->KH == KH) return t;
+        if (t->dtype == dtype && t->M == M && t->N == N && t->K == K && t->KH == KH && t->variant == variant) return t;
     return nullptr;
 }
 
@@ -320,12 +322,12 @@ int pick_tile(const madm_conv2d_args* a) {
     const int halo_default = (a->N % 128 == 0 || a->N >= 512) ? 4 : 5;
     if (a->gn_scale) {   // fused GroupNorm exists only in the halo kernel
         if (g_tile_override == 4 || g_tile_override == 5) return g_tile_override;
-        if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH))
+        if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH, variant_of(a)))
             if (t->tile == 4 || t->tile == 5) return t->tile;
         return halo_default;
     }
     if (g_tile_override > 0 && (is_igemm_tile(g_tile_override) || halo_ok)) return g_tile_override;
-    if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH))
+    if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH, variant_of(a)))
         if (is_igemm_tile(t->tile) || halo_ok) return t->tile;
     if (halo_ok && M >= 2048) return halo_default;
     return heuristic_tile(M, a->N);
@@ -441,7 +443,7 @@ int madm_conv2d_suggest_splitk(const madm_conv2d_args* a) {
     const int Ktot = a->KH * a->KW * (a->C1 + a->C2);
     const int nk = Ktot / bke;
     const int chosen = pick_tile(a);
-    if (const Tuned* t = find_tuned(a->dtype, M, a->N, Ktot, a->KH))
+    if (const Tuned* t = find_tuned(a->dtype, M, a->N, Ktot, a->KH, variant_of(a)))
         if (t->tile == chosen) return t->splitk;
     int bm, bn;
     tile_dims(pick_tile(a), bm, bn);

@@ -8,19 +8,27 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INC = os.path.join(ROOT, "madm_amd", "csrc", "igemm_tuned.inc")
-ROW = re.compile(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},")
+ROW = re.compile(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},")
+
+
+LINE = re.compile(r"^M(\d+) N(\d+) K(\d+) k(\d+) s\d+((?: up)?(?: cat)?(?: st)?(?: gn)?)\s+\d+\s+t\d+/sk\d+\s+[\d.]+\s+t(\d+)/sk(\d+)")
 
 
 def rows_of(path):
-    out, on = [], False
+    """Rows from the tuner's per-shape table (dtype bf16): the first (most expensive) occurrence of a key wins."""
+    out, seen = [], set()
     for line in open(path):
-        if "rows for igemm_tuned.inc" in line:
-            on = True
+        m = LINE.match(line.strip())
+        if not m:
             continue
-        m = ROW.match(line.strip())
-        if on and m:
-            out.append(tuple(int(x) for x in m.groups()))
-    return out
+        M, N, K, KH = (int(m.group(i)) for i in range(1, 5))
+        variant = 1 if " gn" in m.group(5) else (2 if " up" in m.group(5) else 0)
+        key = (1, M, N, K, KH, variant)
+        if key in seen:
+            continue
+        seen.add(key)
+        out.append(key + (int(m.group(6)), int(m.group(7))))
+    return sorted(out)
 
 
 def main():
@@ -35,18 +43,18 @@ def main():
             m = ROW.match(line.strip())
             if on and m:
                 ev.append(tuple(int(x) for x in m.groups()))
-    keys = {r[:5] for r in extract}
-    ev = [r for r in ev if r[:5] not in keys]
+    keys = {r[:6] for r in extract}
+    ev = [r for r in ev if r[:6] not in keys]
     with open(INC, "w") as f:
-        f.write("// {dtype (0 f32, 1 bf16), M, N, K, KH, tile (1=128x128, 2=128x64, 3=64x64 igemm; 4 = halo conv3x3 x128, "
+        f.write("// {dtype (0 f32, 1 bf16), M, N, K, KH, variant (0 plain, 1 GroupNorm-fused, 2 upsample), tile (1=128x128, 2=128x64, 3=64x64 igemm; 4 = halo conv3x3 x128, "
                 "5 = halo x64; 6 = 64x64 igemm with the 8-deep prefetch), splitk}\n")
         f.write("// measured by tools/tune_insitu.py on MI355X (whole eager forwards, cold weights), bf16, round 1\n")
         f.write("// -- feature extractor, bs=2, 512x512 (BASELINE configs[1])\n")
         for r in extract:
-            f.write("{%d, %d, %d, %d, %d, %d, %d},\n" % r)
+            f.write("{%d, %d, %d, %d, %d, %d, %d, %d},\n" % r)
         f.write("// -- full inference forward, bs=1, 512x512, RGB->Depth config (BASELINE configs[2]): additional shapes\n")
         for r in ev:
-            f.write("{%d, %d, %d, %d, %d, %d, %d},\n" % r)
+            f.write("{%d, %d, %d, %d, %d, %d, %d, %d},\n" % r)
     print(f"{len(extract)} extract rows, {len(ev)} eval rows -> {INC}")
 
 

@@ -96,22 +96,23 @@ def main():
         tot_cur += cur
         tot_best += best[1]
         mm = re.match(r"M(\d+) N(\d+) K(\d+) k(\d+)", key)
+        variant = 1 if " gn" in key else (2 if " up" in key else 0)
         rows.append((best[1], key, len(idxs), cur_cfg, cur / len(idxs), best[0], best[1] / len(idxs),
-                     tuple(int(x) for x in mm.groups())))
+                     tuple(int(x) for x in mm.groups()) + (variant,)))
     rows.sort(reverse=True)
     print(f"current table {tot_cur / 1e3:.3f} ms -> best per shape {tot_best / 1e3:.3f} ms (HIP-event time, eager)")
     print(f"{'shape':42s} {'n':>3s} {'current':>10s} {'us':>8s} {'best':>10s} {'us':>8s}")
     for r in rows:
         print(f"{r[1]:42s} {r[2]:3d}  t{r[3][0]}/sk{r[3][1]:<3d} {r[4]:8.1f}   t{r[5][0]}/sk{r[5][1]:<3d} {r[6]:8.1f}")
-    print("\n// ---- rows for igemm_tuned.inc: {dtype, M, N, K, KH, tile, splitk}")
+    print("\n// ---- rows for igemm_tuned.inc: {dtype, M, N, K, KH, variant, tile, splitk}")
     seen = set()
     dt = 1 if args.dtype == "bf16" else 0
-    for r in sorted(rows, key=lambda r: (r[7], 0 if " gn" in r[1] else 1)):
-        if r[7] in seen:
+    for r in sorted(rows, key=lambda r: r[7]):
+        if r[7] in seen:      # same GEMM shape and variant reached through a different stride / source layout
             continue
         seen.add(r[7])
-        M, N, K, KH = r[7]
-        print(f"{{{dt}, {M}, {N}, {K}, {KH}, {r[5][0]}, {r[5][1]}}},")
+        M, N, K, KH, variant = r[7]
+        print(f"{{{dt}, {M}, {N}, {K}, {KH}, {variant}, {r[5][0]}, {r[5][1]}}},")
 
 
 if __name__ == "__main__":
