@@ -102,14 +102,20 @@ typedef struct {
     double* stats;        /* NULL, or f64 [B][N][2], zeroed by the caller: receives the per-(image, channel)
                            * sum and sum of squares of the stored output -- the statistics pass of the
                            * GroupNorm that consumes this tensor, fused into the producer's epilogue */
-    /* fused GroupNorm(+SiLU) of the INPUT (3x3 / stride 1 / pad 1 convs on maps >= 8x16 only, see
-     * madm_conv2d_can_fuse_groupnorm): the conv reads RAW sources and applies
-     * y = act(x * gn_scale[b][c] + gn_shift[b][c]) while staging its LDS halo tile, zero padding after the
-     * activation; gn_scale / gn_shift are f32 [B][C1+C2] from madm_groupnorm_finalize, NULL = off;
+    /* fused GroupNorm(+act) of the INPUT (3x3 / stride 1 / pad 1 convs on maps >= 8x16 only, see
+     * madm_conv2d_can_fuse_groupnorm): the conv reads RAW sources, folds the per-channel sums of the sources
+     * (gn_sums1: f64 [B][C1][2], gn_sums2: f64 [B][C2][2] for the second source; the "stats" output of the producing
+     * convs or madm_groupnorm_stats) into group mean / rstd in its prologue -- no finalize launch -- and applies
+     * y = act((x - mean_g) * rstd_g * gn_gamma[c] + gn_beta[c]) while staging its LDS halo tile, zero padding after
+     * the activation.  gn_sums1 NULL = off; gn_groups <= 32 and divides C1 + C2; gn_gamma / gn_beta f32 [C1 + C2];
      * gn_act: madm_act (SiLU: ResnetBlock2D norm1/norm2 + nonlinearity, conv_norm_out + conv_act; ReLU: d2
      * BottleneckBlock conv1.norm + relu before its 3x3 conv2) */
-    const float* gn_scale;
-    const float* gn_shift;
+    const double* gn_sums1;
+    const double* gn_sums2;
+    const float* gn_gamma;
+    const float* gn_beta;
+    int gn_groups;
+    float gn_eps;
     int gn_act;
     int splitk;           /* >=1; >1 needs workspace (f32 [splitk][M][N]) */
     void* workspace;
@@ -120,10 +126,11 @@ size_t madm_conv2d_workspace_bytes(const madm_conv2d_args* a);
 /* heuristic split-K for the MI355X grid (256 CUs); returns 1 when the tile grid already fills it */
 int madm_conv2d_suggest_splitk(const madm_conv2d_args* a);
 int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream);
-/* 1 when these arguments can take gn_scale / gn_shift (the LDS halo-tile 3x3 kernel applies), else 0. */
+/* 1 when these arguments can take gn_sums1 / gn_gamma / ... (the LDS halo-tile 3x3 kernel applies), else 0. */
 int madm_conv2d_can_fuse_groupnorm(const madm_conv2d_args* a);
 /* which kernel instance madm_conv2d_fwd will launch for these arguments: 1 = igemm 128x128,
- * 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 x128 channels, 5 = halo conv3x3 x64 channels
+ * 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 x128 channels, 5 = halo conv3x3 x64 channels,
+ * 6 = igemm 64x64 with the 8-deep prefetch
  * (used by bench.py to attribute time). */
 int madm_conv2d_pick_tile(const madm_conv2d_args* a);
 /* tuning/debug aid: force the workgroup tile (0 = tuned table then heuristic, -1 = heuristic only,
@@ -154,7 +161,7 @@ int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int 
                          const void* residual, int ldres, void* stream);
 
 /* channel sums -> the per-(image, channel) affine of the GroupNorm, scale/shift f32 [B][Ctot]:
- * y = x * scale + shift == (x - mean_g) * rstd_g * gamma + beta; input of madm_conv2d_args.gn_scale/gn_shift. */
+ * y = x * scale + shift == (x - mean_g) * rstd_g * gamma + beta (what the fused conv computes in its prologue). */
 int madm_groupnorm_finalize(int B, int HW, int Ctot, int G, const double* sums1, int C1,
                             const double* sums2, const float* gamma, const float* beta, float eps,
                             float* scale, float* shift, void* stream);

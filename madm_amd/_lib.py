@@ -48,7 +48,8 @@ class Conv2dArgs(ctypes.Structure):
         ("out_f32", c_int),
         ("epilogue", c_int),
         ("stats", c_void_p),
-        ("gn_scale", c_void_p), ("gn_shift", c_void_p), ("gn_act", c_int),
+        ("gn_sums1", c_void_p), ("gn_sums2", c_void_p), ("gn_gamma", c_void_p), ("gn_beta", c_void_p),
+        ("gn_groups", c_int), ("gn_eps", ctypes.c_float), ("gn_act", c_int),
         ("splitk", c_int),
         ("workspace", c_void_p),
         ("workspace_bytes", c_size_t),

@@ -16,6 +16,9 @@
 namespace {
 
 constexpr int TH = 8, TW = 16, HWD = TW + 2, HPIX = (TH + 2) * HWD;  // 180 halo pixels
+#ifdef C3_STAMPS
+__device__ unsigned long long g_c3_stamps[2048];
+#endif
 
 template <typename T, int EPC>
 __device__ __forceinline__ u32x4 gn_act_chunk(u32x4 raw, const float* sc, const float* sh, int act) {
@@ -27,8 +30,8 @@ __device__ __forceinline__ u32x4 gn_act_chunk(u32x4 raw, const float* sc, const 
     return __builtin_bit_cast(u32x4, f32_to_chunk<T>(f));
 }
 
-template <typename T, int BN, bool FUSE>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
+template <typename T, int BN, bool FUSE, int NWS>
+__global__ __launch_bounds__(256, (NWS == 2 || BN == 64) ? 2 : 1) void conv3x3_halo_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;
     constexpr int MI = 4, NI = BN / 32;     // wave tile: 4 patch rows (64 px) x BN/2 channels
@@ -39,6 +42,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p, in
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     u32x4* halo = reinterpret_cast<u32x4*>(smem_raw);   // [2][HALO_U4]
     u32x4* wlds = halo + 2 * HALO_U4;                   // [2][W_U4]
+    float2* gstat = reinterpret_cast<float2*>(wlds + 2 * W_U4);   // [32] {mean, rstd} per group (FUSE)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -85,7 +89,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p, in
     const int ck1 = (int)(((long long)nchunks * (z + 1)) / p.splitk);
     const int S = (ck1 - ck0) * 9;
 
-    u32x4 hr[HI], rw0[RB], rw1[RB];
+    static_assert(NWS >= 2 && NWS % 2 == 0, "the weight ring must have an even number of stages");
+    // rw[t % NWS] = weight tile t, NWS - 1 tiles ahead of the MFMAs.  Deeper rings (NWS = 4, 6) and a GroupNorm
+    // transform spread over the taps were measured on MI355X and did not pay (round-1 notes in DESIGN.md): the step is
+    // bound by its non-MFMA phases (LDS store, barrier), not by the weight latency.
+    u32x4 hr[HI], rw[NWS][RB];
     float sc[EPC], sh[EPC];
 #pragma unroll
     for (int j = 0; j < EPC; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
@@ -102,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p, in
             hr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, pixoff[i] >= 0 ? off_ : OOB, 0, 0);  \
         }                                                                                           \
         if (FUSE) {                                                                                 \
-            const float* gs_ = p.gn_scale + (size_t)b * p.Ctot + c0_ + cpos * EPC;                  \
-            const float* gh_ = p.gn_shift + (size_t)b * p.Ctot + c0_ + cpos * EPC;                  \
+            const float* gs_ = p.gn_gamma + c0_ + cpos * EPC;   /* raw gamma / beta; C3_STORE_HALO */     \
+            const float* gh_ = p.gn_beta + c0_ + cpos * EPC;    /* turns them into scale / shift   */     \
             _Pragma("unroll") for (int j = 0; j < EPC; j += 4) {                                    \
                 const float4 a_ = *reinterpret_cast<const float4*>(gs_ + j);                        \
                 const float4 b_ = *reinterpret_cast<const float4*>(gh_ + j);                        \
@@ -113,9 +121,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p, in
         }                                                                                           \
     }
 
-#define C3_STORE_HALO(buf)                                                                          \
+#define C3_STORE_HALO(buf, ck_)                                                                     \
     {                                                                                               \
         u32x4* dst_ = halo + (buf) * HALO_U4;                                                       \
+        if (FUSE) {                                                                                 \
+            const unsigned cb_ = (unsigned)((ck_) * BKE + cpos * EPC);                              \
+            _Pragma("unroll") for (int j = 0; j < EPC; ++j) {                                       \
+                const float2 st_ = gstat[__umulhi(cb_ + j, p.gn_magic)];                            \
+                const float s_ = st_.y * sc[j];                                                     \
+                sh[j] = sh[j] - st_.x * s_;                                                         \
+                sc[j] = s_;                                                                         \
+            }                                                                                       \
+        }                                                                                           \
         _Pragma("unroll") for (int i = 0; i < HI; ++i) {                                            \
             if (hpos[i] >= 0) {                                                                     \
                 u32x4 v_ = hr[i];                                                                   \
@@ -152,20 +169,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p, in
 
     if (S > 0) {
         C3_LOAD_HALO(ck0);
-        C3_LOAD_W(rw0);
-        if (S > 1) C3_LOAD_W(rw1);
-        C3_STORE_HALO(0);
-        C3_STORE_W(0, rw0);
+        C3_LOAD_W(rw[0]);
+        if constexpr (NWS == 2) {
+            if (S > 1) C3_LOAD_W(rw[1]);
+        } else {
+#pragma unroll
+            for (int u = 1; u < NWS; ++u)
+                if (u < S) C3_LOAD_W(rw[u]);
+        }
+        if (FUSE) {   // GroupNorm finalize of this image while the first tiles are in flight
+            gn_fold_groups(p, b, gstat);
+            __syncthreads();
+        }
+        C3_STORE_HALO(0, ck0);
+        C3_STORE_W(0, rw[0]);
     }
     __syncthreads();
 
+#ifdef C3_EXP_NOPIN
+#define C3_PIN()
+#else
+#define C3_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef C3_EXP_SETPRIO
+#define C3_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define C3_PRIO(x)
+#endif
+#ifdef C3_STAMPS   // tools/exp: shader-clock stamps of block 0 / wave 0 at four points of every step
+#define C3_STAMP(s_, k_)                                                                            \
+    if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0 && (s_) < 512)                               \
+        g_c3_stamps[(s_) * 4 + (k_)] = __builtin_readcyclecounter();
+#else
+#define C3_STAMP(s_, k_)
+#endif
     int ck = ck0, tap = 0;   // the tile being computed
 #define C3_STEP(s_, CUR, RL_, RS_)                                                                  \
     {                                                                                               \
         const bool next_chunk_ = (ck + 1 < ck1);                                                    \
-        if ((s_) + 2 < S) C3_LOAD_W(RL_);                                                           \
+        C3_STAMP(s_, 0);                                                                            \
+        if ((s_) + NWS < S) C3_LOAD_W(RL_);                                                           \
         if (tap == 0 && next_chunk_) C3_LOAD_HALO(ck + 1);                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
+        C3_PIN();                                                                                   \
+        C3_PRIO(1);                                                                                 \
         {                                                                                           \
             const u32x4* hsrc_ = halo + ((ck - ck0) & 1) * HALO_U4;                                 \
             const u32x4* wsrc_ = wlds + (CUR) * W_U4;                                               \
@@ -184,18 +230,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p, in
                     _Pragma("unroll") for (int j = 0; j < NI; ++j) mma16<T>(wf_[j], af_[i], acc[i][j]); \
             }                                                                                       \
         }                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
+        C3_PRIO(0);                                                                                 \
+        C3_PIN();                                                                                   \
+        C3_STAMP(s_, 1);                                                                            \
         if ((s_) + 1 < S) C3_STORE_W((CUR) ^ 1, RS_);                                               \
-        if (tap == 8 && next_chunk_) C3_STORE_HALO(((ck - ck0) + 1) & 1);                           \
+        if (tap == 8 && next_chunk_) C3_STORE_HALO(((ck - ck0) + 1) & 1, ck + 1);                   \
+        C3_STAMP(s_, 2);                                                                            \
         __syncthreads();                                                                            \
+        C3_STAMP(s_, 3);                                                                            \
         if (++tap == 9) { tap = 0; ++ck; }                                                          \
     }
     int s = 0;
-    for (; s + 1 < S; s += 2) {
-        C3_STEP(s, 0, rw0, rw1);
-        C3_STEP(s + 1, 1, rw1, rw0);
+    if constexpr (NWS == 2) {
+        for (; s + 1 < S; s += 2) {
+            C3_STEP(s, 0, rw[0], rw[1]);
+            C3_STEP(s + 1, 1, rw[1], rw[0]);
+        }
+        if (s < S) C3_STEP(s, 0, rw[0], rw[1]);
+    } else {
+        for (; s + NWS <= S; s += NWS) {
+#pragma unroll
+            for (int u = 0; u < NWS; ++u) C3_STEP(s + u, u & 1, rw[u], rw[(u + 1) % NWS]);
+        }
+#pragma unroll
+        for (int u = 0; u < NWS - 1; ++u)
+            if (s + u < S) C3_STEP(s + u, u & 1, rw[u], rw[(u + 1) % NWS]);
     }
-    if (s < S) C3_STEP(s, 0, rw0, rw1);
 #undef C3_STEP
 #undef C3_LOAD_W
 #undef C3_STORE_W
@@ -259,11 +319,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmP p, in
     }
 }
 
-template <typename T, int BN, bool FUSE>
+template <typename T, int BN, bool FUSE, int NWS>
 int launch_one(const IgemmP& p0, hipStream_t s) {
     IgemmP p = p0;
-    constexpr size_t lds = (size_t)(2 * HPIX * 8 + 2 * BN * 8) * 16;
-    auto kern = conv3x3_halo_kernel<T, BN, FUSE>;
+    constexpr size_t lds = (size_t)(2 * HPIX * 8 + 2 * BN * 8) * 16 + 32 * sizeof(float2);
+    auto kern = conv3x3_halo_kernel<T, BN, FUSE, NWS>;
     static bool attr_set = false;
     if (!attr_set) {
         if (lds > 64 * 1024) {
@@ -287,9 +347,14 @@ int launch_one(const IgemmP& p0, hipStream_t s) {
 
 template <typename T>
 int launch_conv3x3_halo(const IgemmP& p, int bn, hipStream_t s) {
-    const bool fuse = p.gn_scale != nullptr;
-    if (bn == 128) return fuse ? launch_one<T, 128, true>(p, s) : launch_one<T, 128, false>(p, s);
-    return fuse ? launch_one<T, 64, true>(p, s) : launch_one<T, 64, false>(p, s);
+    const bool fuse = p.gn_sums1 != nullptr;
+    if (bn == 128) return fuse ? launch_one<T, 128, true, 2>(p, s) : launch_one<T, 128, false, 2>(p, s);
+    return fuse ? launch_one<T, 64, true, 2>(p, s) : launch_one<T, 64, false, 2>(p, s);
 }
+#ifdef C3_STAMPS
+extern "C" int madm_debug_read_c3_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c3_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 template int launch_conv3x3_halo<float>(const IgemmP&, int, hipStream_t);
 template int launch_conv3x3_halo<bf16_t>(const IgemmP&, int, hipStream_t);

@@ -283,12 +283,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
 
 int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
 inline bool is_igemm_tile(int t) { return t <= 3 || t == 6; }
+inline bool is_halo_tile(int t) { return t == 4 || t == 5; }
 
 // Launch configurations measured on MI355X by tools/tune_insitu.py for the layer shapes of the SD-v1-4
 // feature extractor at bs=2, 512x512 (any other shape falls back to the heuristics below).
 // variant: 0 = plain, 1 = GroupNorm fused into the halo load, 2 = nearest-2x upsample gather
 struct Tuned { int dtype, M, N, K, KH, variant, tile, splitk; };
-inline int variant_of(const madm_conv2d_args* a) { return a->gn_scale ? 1 : (a->upsample ? 2 : 0); }
+inline int variant_of(const madm_conv2d_args* a) { return a->gn_sums1 ? 1 : (a->upsample ? 2 : 0); }
 const Tuned g_tuned[] = {
 #include "igemm_tuned.inc"
     {-1, 0, 0, 0, 0, 0, 0, 0}};
@@ -320,10 +321,10 @@ int pick_tile(const madm_conv2d_args* a) {
     const int M = a->B * a->OH * a->OW, K = a->KH * a->KW * (a->C1 + a->C2);
     const bool halo_ok = halo_eligible(a);
     const int halo_default = (a->N % 128 == 0 || a->N >= 512) ? 4 : 5;
-    if (a->gn_scale) {   // fused GroupNorm exists only in the halo kernel
-        if (g_tile_override == 4 || g_tile_override == 5) return g_tile_override;
+    if (a->gn_sums1) {   // fused GroupNorm exists only in the halo kernel
+        if (is_halo_tile(g_tile_override)) return g_tile_override;
         if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH, variant_of(a)))
-            if (t->tile == 4 || t->tile == 5) return t->tile;
+            if (is_halo_tile(t->tile)) return t->tile;
         return halo_default;
     }
     if (g_tile_override > 0 && (is_igemm_tile(g_tile_override) || halo_ok)) return g_tile_override;
@@ -359,7 +360,8 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     p.in1 = (const char*)a->in1; p.in2 = (const char*)a->in2; p.w = (const char*)a->w;
     p.bias = a->bias; p.rowvec = a->rowvec; p.residual = (const char*)a->residual;
     p.out = (char*)a->out; p.ws = (float*)a->workspace; p.stats = a->stats;
-    p.gn_scale = nullptr; p.gn_shift = nullptr; p.act = 0;
+    p.gn_sums1 = nullptr; p.gn_sums2 = nullptr; p.gn_gamma = nullptr; p.gn_beta = nullptr;
+    p.gn_G = 0; p.gn_eps = 0.f; p.gn_magic = 0; p.act = 0;
     MADM_REQUIRE(!a->stats || a->epilogue != MADM_EPI_GEGLU, "conv2d: fused statistics cannot follow GEGLU");
     p.C1 = a->C1; p.C2 = a->C2; p.Ctot = a->C1 + a->C2;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW;
@@ -398,7 +400,7 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
     int bm, bn;
     tile_dims(t, bm, bn);
     int rc;
-    if (t == 4 || t == 5) {
+    if (is_halo_tile(t)) {
         rc = launch_conv3x3_halo<T>(p, bn, s);
     } else {
         p.tilesN = (p.N + bn - 1) / bn;
@@ -467,13 +469,23 @@ int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream) {
                      a->workspace_bytes);
     }
     const int t = pick_tile(a);
-    if (a->gn_scale) {
-        MADM_REQUIRE(a->gn_shift && halo_eligible(a),
-                     "conv2d: fused GroupNorm needs gn_shift and a 3x3 / stride-1 / pad-1 conv on a map of at least 8x16 "
+    if (a->gn_sums1) {
+        MADM_REQUIRE(halo_eligible(a),
+                     "conv2d: fused GroupNorm needs a 3x3 / stride-1 / pad-1 conv on a map of at least 8x16 "
                      "(use madm_groupnorm_apply otherwise; madm_conv2d_can_fuse_groupnorm tells)");
-        p.gn_scale = a->gn_scale; p.gn_shift = a->gn_shift; p.act = a->gn_act;
+        MADM_REQUIRE(a->gn_gamma && a->gn_beta && (a->C2 == 0 || a->gn_sums2), "conv2d: fused GroupNorm needs gamma, beta "
+                     "and the sums of every source");
+        MADM_REQUIRE(a->gn_groups > 0 && a->gn_groups <= 32 && p.Ctot % a->gn_groups == 0 && a->gn_eps > 0.f,
+                     "conv2d: fused GroupNorm: bad groups=%d (C=%d) / eps", a->gn_groups, p.Ctot);
+        MADM_REQUIRE(a->gn_act >= 0 && a->gn_act <= 2, "conv2d: bad gn_act %d", a->gn_act);
+        const unsigned cpg = (unsigned)(p.Ctot / a->gn_groups);
+        const unsigned magic = (unsigned)((0x100000000ull + cpg - 1) / cpg);   // c / cpg == umulhi(c, magic), checked:
+        for (unsigned c = 0; c < (unsigned)p.Ctot; ++c)
+            MADM_REQUIRE((unsigned)(((unsigned long long)c * magic) >> 32) == c / cpg, "conv2d: group index magic failed");
+        p.gn_sums1 = a->gn_sums1; p.gn_sums2 = a->gn_sums2; p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta;
+        p.gn_G = a->gn_groups; p.gn_eps = a->gn_eps; p.gn_magic = magic; p.act = a->gn_act;
     }
-    if (t >= 4) {   // the halo kernel splits K by whole channel chunks
+    if (is_halo_tile(t)) {   // the halo kernel splits K by whole channel chunks
         const int nchunks = p.Ctot / ((a->dtype == MADM_BF16) ? 64 : 32);
         if (p.splitk > nchunks) p.splitk = nchunks;
     }

@@ -11,9 +11,58 @@ struct IgemmP {
     int C1, C2, Ctot, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
     int N, K, M, ldr, ldo, ldrv, epilogue, splitk, tilesN, nk, ld1, ld2, ldw, out_f32;
     unsigned bytes1, bytes2, bytesw;
-    // halo-tile 3x3 conv only: fused GroupNorm(+SiLU) of the INPUT, y = act(x * gn_scale[b][c] + gn_shift[b][c])
-    const float* gn_scale; const float* gn_shift; int act;
+    // halo-tile 3x3 conv only: fused GroupNorm(+act) of the INPUT, finalized in the kernel from the per-channel f64
+    // sums of the (one or two) sources: group g = c / cpg == __umulhi(c, gn_magic)
+    const double* gn_sums1; const double* gn_sums2; const float* gn_gamma; const float* gn_beta;
+    int gn_G; float gn_eps; unsigned gn_magic; int act;
 };
+
+// GroupNorm finalize inside the consumer: gstat[g] = {mean_g, rstd_g} of image b from the per-channel sums.
+// All 256 threads: 8 lanes per group, every lane's loads in flight together, xor-shuffle reduction (f64 like
+// gn_apply_kernel / gn_finalize_kernel, so the three agree bit for bit).  The caller synchronises afterwards.
+__device__ __forceinline__ void gn_fold_groups(const IgemmP& p, int b, float2* gstat) {
+    const int G = p.gn_G, cpg = p.Ctot / G, C2 = p.Ctot - p.C1;
+    const double cnt = (double)(p.IH * p.IW) * (double)cpg;
+    for (int g0 = 0; g0 < G; g0 += 32) {
+        const int g = g0 + ((int)threadIdx.x >> 3), l = threadIdx.x & 7;
+        double s = 0.0, q = 0.0;
+        if (g < G) {
+            constexpr int UF = 10;
+            double sv[UF], qv[UF];
+#pragma unroll
+            for (int i = 0; i < UF; ++i) {
+                const int ch = g * cpg + l + 8 * i;
+                sv[i] = 0.0;
+                qv[i] = 0.0;
+                if (ch < (g + 1) * cpg) {
+                    const double* src = (ch < p.C1) ? p.gn_sums1 + ((size_t)b * p.C1 + ch) * 2
+                                                    : p.gn_sums2 + ((size_t)b * C2 + (ch - p.C1)) * 2;
+                    sv[i] = src[0];
+                    qv[i] = src[1];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < UF; ++i) { s += sv[i]; q += qv[i]; }
+            for (int ch = g * cpg + l + 8 * UF; ch < (g + 1) * cpg; ch += 8) {
+                const double* src = (ch < p.C1) ? p.gn_sums1 + ((size_t)b * p.C1 + ch) * 2
+                                                : p.gn_sums2 + ((size_t)b * C2 + (ch - p.C1)) * 2;
+                s += src[0];
+                q += src[1];
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s += __shfl_xor(s, o);
+            q += __shfl_xor(q, o);
+        }
+        if (g < G && l == 0) {
+            const double mean = s / cnt;
+            double var = q / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            gstat[g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.gn_eps)));
+        }
+    }
+}
 
 // applies bias / time row / GEGLU / residual, stores 4 (2 for GEGLU) outputs, returns the stored values
 template <typename T>

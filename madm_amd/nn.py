@@ -135,9 +135,7 @@ class Conv2d(_Packed):
                         s_.stats = ops.new_chsums(s_.B, s_.C, s_.t.device)
                         ops.groupnorm_stats(s_.t, s_.B, s_.HW, s_.stats)
                     sts.append(s_.stats)
-                scale, shift = ops.groupnorm_finalize(sts, x.B, x.HW, norm.num_groups, norm.weight.detach(),
-                                                      norm.bias.detach(), norm.eps)
-                gn = (scale, shift, act)
+                gn = (sts, norm.weight.detach(), norm.bias.detach(), norm.num_groups, norm.eps, act)
             else:
                 x = norm(x, act=act, x2=x2)
                 x2 = None

@@ -63,7 +63,7 @@ def can_fuse_groupnorm(IH, IW, KH, stride, pad, asym_pad, upsample):
 
 def groupnorm_finalize(stats, B, HW, G, gamma, beta, eps):
     """Channel sums of one or two concatenated sources -> (scale, shift) f32 [B, Ctot] with
-    x * scale + shift == GroupNorm(x) (input of conv2d(..., gn=...))."""
+    x * scale + shift == GroupNorm(x) (what conv2d(..., gn=...) computes in its own prologue; kept as a utility)."""
     _need_cuda(gamma, beta, *stats)
     C1 = stats[0].shape[1]
     Ctot = sum(st.shape[1] for st in stats)
@@ -156,11 +156,17 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     if stats is not None:
         assert stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() == B * N * 2
         a.stats = stats.data_ptr()
-    if gn is not None:   # (scale [B, C1+C2] f32, shift, act): GroupNorm(+SiLU) of the input fused into the conv
-        gs, gh, act = gn
-        assert gs.dtype == torch.float32 and gh.dtype == torch.float32 and gs.is_contiguous() and gh.is_contiguous()
-        assert gs.numel() == B * (C1 + C2) and gh.numel() == gs.numel()
-        a.gn_scale, a.gn_shift, a.gn_act = gs.data_ptr(), gh.data_ptr(), _act_code(act=act)
+    if gn is not None:   # (sums list, gamma, beta, groups, eps, act): GroupNorm(+act) of the input fused into the conv
+        sums, gamma, beta, groups, eps, act = gn
+        _need_cuda(gamma, beta, *sums)
+        assert len(sums) == (2 if x2 is not None else 1) and gamma.numel() == C1 + C2 and beta.numel() == C1 + C2
+        assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.is_contiguous() and beta.is_contiguous()
+        for st_, c_ in zip(sums, (C1, C2)):
+            assert st_.dtype == torch.float64 and st_.is_contiguous() and st_.numel() == B * c_ * 2
+        a.gn_sums1 = sums[0].data_ptr()
+        a.gn_sums2 = sums[1].data_ptr() if len(sums) > 1 else None
+        a.gn_gamma, a.gn_beta = gamma.data_ptr(), beta.data_ptr()
+        a.gn_groups, a.gn_eps, a.gn_act = int(groups), float(eps), _act_code(act=act)
     a.splitk = 1
     if FORCE_SPLITK is not None and splitk is None:
         nk = KH * KW * (C1 + C2) // k_tile(x1.dtype)

@@ -196,8 +196,7 @@ class AutoencoderKL(_Packed):
                 h.stats = ops.new_chsums(h.B, h.C, h.t.device)
                 ops.groupnorm_stats(h.t, h.B, h.HW, h.stats)
             no = enc.conv_norm_out
-            gn = (*ops.groupnorm_finalize([h.stats], h.B, h.HW, no.num_groups, no.weight.detach(), no.bias.detach(),
-                                          no.eps), True)
+            gn = ([h.stats], no.weight.detach(), no.bias.detach(), no.num_groups, no.eps, True)
         else:
             h = enc.conv_norm_out(h, silu=True)
         o = ops.conv2d(h.t, wp, h.B, h.H, h.W, N=wp.shape[0], KH=3, KW=3, pad_t=1, pad_l=1, bias=bp, gn=gn)

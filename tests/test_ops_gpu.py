@@ -46,6 +46,9 @@ CONV_CASES = [
     ("halo_concat", 2, [128, 64], 8, 16, 128, 3, 1, "same", False, 5, 1),
     ("halo_splitk", 2, [256], 8, 16, 64, 3, 1, "same", False, 5, 2),
     ("halo_auto", 1, [64], 64, 64, 128, 3, 1, "same", False, 0, None),
+    # 6 = igemm 64x64 with the 8-deep prefetch ring (K long enough to wrap it, and a split K shorter than it)
+    ("deep_igemm64", 2, [640], 8, 8, 320, 1, 1, "same", False, 6, 1),
+    ("deep_igemm64_splitk", 2, [1280], 4, 4, 128, 3, 1, "same", False, 6, 3),
 ]
 
 
@@ -187,7 +190,7 @@ def test_conv_fused_groupnorm_stats(cuda, dtype, case):
                          ids=["x128", "x64", "ragged_affine", "concat", "concat_straddle"])
 def test_conv_fused_groupnorm_input(cuda, dtype, case):
     """conv3x3(silu(GroupNorm([x | skip]))) with the normalisation folded into the conv's LDS halo load
-    (statistics -> madm_groupnorm_finalize -> gn_scale/gn_shift) equals the unfused torch composition,
+    (channel sums -> group mean / rstd in the conv's own prologue) equals the unfused torch composition,
     including the zero padding applied AFTER the activation."""
     from madm_amd import ops, packing
     from madm_amd._lib import lib
@@ -208,17 +211,37 @@ def test_conv_fused_groupnorm_input(cuda, dtype, case):
         st = torch.zeros((B, t.shape[1], 2), dtype=torch.float64, device="cuda")
         ops.groupnorm_stats(t, B, H * W, st)
         sts.append(st)
-    scale, shift = ops.groupnorm_finalize(sts, B, H * W, 32, gamma.cuda(), beta.cuda(), 1e-5)
     wp = packing.pack_conv_weight(w, dtype, kt, splits=cins).cuda()
     lib.madm_debug_set_conv_tile(tile)
     try:
         out = ops.conv2d(toks[0], wp, B, H, W, N=Cout, x2=toks[1] if len(toks) > 1 else None, KH=3, KW=3, pad_t=1,
-                         pad_l=1, bias=bias.cuda(), gn=(scale, shift, act))
+                         pad_l=1, bias=bias.cuda(), gn=(sts, gamma.cuda(), beta.cuda(), 32, 1e-5, act))
     finally:
         lib.madm_debug_set_conv_tile(0)
     e, l2 = rel_err(from_tokens(out, B, H, W), ref)
     # bf16: the fused path rounds the activated input once to bf16 exactly like the unfused one
     assert e < (3e-5 if dtype == torch.float32 else 2e-2), f"{e:.3e} {l2:.3e}"
+
+
+def test_groupnorm_finalize_utility(cuda):
+    """madm_groupnorm_finalize (stand-alone form of what the fused conv does in its prologue): x * scale + shift
+    equals GroupNorm(x) for a two-source concat whose groups straddle the boundary."""
+    from madm_amd import ops
+    B, cins, H, W = 2, [1280, 640], 4, 6
+    xs = [_gen((B, c, H, W), 30 + i) * (1.0 + i) + 0.5 * i for i, c in enumerate(cins)]
+    C = sum(cins)
+    gamma, beta = 1.0 + 0.2 * _gen((C,), 2), 0.3 * _gen((C,), 3)
+    ref = F.group_norm(torch.cat(xs, 1), 32, gamma, beta, eps=1e-5)
+    sts = []
+    for x in xs:
+        t = to_tokens(x, torch.float32)
+        st = torch.zeros((B, t.shape[1], 2), dtype=torch.float64, device="cuda")
+        ops.groupnorm_stats(t, B, H * W, st)
+        sts.append(st)
+    scale, shift = ops.groupnorm_finalize(sts, B, H * W, 32, gamma.cuda(), beta.cuda(), 1e-5)
+    got = torch.cat(xs, 1) * scale.cpu()[:, :, None, None] + shift.cpu()[:, :, None, None]
+    e, l2 = rel_err(got, ref)
+    assert e < 1e-5, f"{e:.3e} {l2:.3e}"
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--residual", action="store_true")
     ap.add_argument("--rotate", type=int, default=1, help="cycle through this many weight buffers (cold weights, as in the model)")
     ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--graph", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     args = ap.parse_args()
@@ -38,7 +39,9 @@ def main():
     bias = torch.randn(Cout, device="cuda")
     gn = None
     if args.gn:
-        gn = (torch.rand((B, Cin), device="cuda") + 0.5, torch.randn((B, Cin), device="cuda") * 0.1, True)
+        sums = torch.zeros((B, Cin, 2), dtype=torch.float64, device="cuda")
+        ops.groupnorm_stats(x, B, H * W, sums)
+        gn = ([sums], torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1, 32, 1e-5, True)
     st = None if args.no_stats else torch.zeros((B, Cout, 2), dtype=torch.float64, device="cuda")
     lib.madm_debug_set_conv_tile(args.tile)
     res = torch.randn((B * H * W, Cout), device="cuda").to(dtype) if args.residual else None
@@ -53,10 +56,21 @@ def main():
         run()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(args.reps):
-        run()
-    e1.record()
+    if args.graph:   # no host launch overhead between the launches (small kernels)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(args.reps):
+                run()
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        g.replay()
+        e1.record()
+    else:
+        e0.record()
+        for _ in range(args.reps):
+            run()
+        e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / args.reps * 1e3
     fl = 2.0 * B * H * W * Cout * k * k * Cin
