@@ -244,20 +244,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
     if (valid) {
         const float* src = p.ws + (size_t)m * p.N + n;
         const size_t slab = (size_t)p.M * p.N;
-        int zz = 0;
-        for (; zz + 4 <= p.splitk; zz += 4) {
-            float4 t0 = *reinterpret_cast<const float4*>(src + (size_t)(zz + 0) * slab);
-            float4 t1 = *reinterpret_cast<const float4*>(src + (size_t)(zz + 1) * slab);
-            float4 t2 = *reinterpret_cast<const float4*>(src + (size_t)(zz + 2) * slab);
-            float4 t3 = *reinterpret_cast<const float4*>(src + (size_t)(zz + 3) * slab);
-            v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w;
-            v[0] += t1.x; v[1] += t1.y; v[2] += t1.z; v[3] += t1.w;
-            v[0] += t2.x; v[1] += t2.y; v[2] += t2.z; v[3] += t2.w;
-            v[0] += t3.x; v[1] += t3.y; v[2] += t3.z; v[3] += t3.w;
-        }
-        for (; zz < p.splitk; ++zz) {
-            float4 t = *reinterpret_cast<const float4*>(src + (size_t)zz * slab);
-            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        // slabs are summed in slab order (bit-reproducible), eight loads in flight per round: the slabs were written
+        // by other XCDs, every round is a full L2-miss latency and the kernel is nothing but those round trips
+        for (int zz = 0; zz < p.splitk; zz += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = (zz + u < p.splitk) ? *reinterpret_cast<const float4*>(src + (size_t)(zz + u) * slab)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (zz + u < p.splitk) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
         }
         v = epilogue_store<T>(p, m, n, v);
         if (want_stats && !one_image) stats_add_elementwise(p, m, n, v);
