@@ -86,7 +86,10 @@ def build_eval_model(dtype, device):
 
 def kernel_profile(model, inputs):
     """Eager pass with HIP events around every MFMA-kernel launch (events recorded on the launch
-    stream).  Returns {kernel: (launches, total_ms, algorithmic_flops)}."""
+    stream).  An event pair costs marker + dispatch latency on top of the kernel it brackets; that cost is
+    measured live with EMPTY brackets on the same stream and subtracted per launch, so the figures line up
+    with rocprofv3's kernel timestamps (profiles/README.md).
+    Returns ({kernel: (launches, total_ms, algorithmic_flops, algorithmic_bytes)}, overhead_us)."""
     from madm_amd import ops
     for _ in range(2):
         model(*inputs)
@@ -98,11 +101,20 @@ def kernel_profile(model, inputs):
         rec = ops.PROFILE
     finally:
         ops.PROFILE = None
+    empty = []
+    for _ in range(64):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        empty.append((a, b))
+    torch.cuda.synchronize()
+    gaps = sorted(a.elapsed_time(b) for a, b in empty)
+    overhead_ms = gaps[len(gaps) // 2]
     agg = {}
     for name, flops, e0, e1, _, nbytes in rec:
         n, ms, fl, by = agg.get(name, (0, 0.0, 0.0, 0))
-        agg[name] = (n + 1, ms + e0.elapsed_time(e1), fl + flops, by + nbytes)
-    return agg
+        agg[name] = (n + 1, ms + max(e0.elapsed_time(e1) - overhead_ms, 1e-4), fl + flops, by + nbytes)
+    return agg, overhead_ms * 1e3
 
 
 def pmc_traffic(kernel, workload):
@@ -199,7 +211,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
 
     prof = None
     if rank == 0 and not args.no_kernel_profile:
-        prof = kernel_profile(model, call)
+        prof, event_overhead_us = kernel_profile(model, call)
 
     if args.no_graph:
         def step():
@@ -274,7 +286,8 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                                "traffic": pmc_traffic(name, args.workload),
                                "algorithmic_bytes": by // n if by else None,
-                               "launches_per_step": n, "kernel_ms_per_step": round(ms, 4)}
+                               "launches_per_step": n, "kernel_ms_per_step": round(ms, 4),
+                               "event_pair_overhead_us_subtracted": round(event_overhead_us, 2)}
             out["kernels"] = {k: {"launches": v[0], "ms": round(v[1], 4),
                                   "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None}
                               for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}

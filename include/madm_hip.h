@@ -310,6 +310,27 @@ int madm_adamw_step(float* p, const float* g, float* m, float* v, size_t n, floa
  * teacher parameters instead of a Python loop over tensors. */
 int madm_ema_update(float* ema, const float* p, size_t n, float alpha, void* stream);
 
+/* ---- label / pseudo-label pipeline of the self-training step, on the device (bit-exact index work) --------------
+ * MTMADISE.convert_label_to_rgb (modeling/meta_arch/mtmadise.py:159-175: label.cpu() -> PIL 'P' image ->
+ * putpalette -> RGB -> (x / 255 - 0.5) / 0.5, valid = label != 255): label i64 [B][HW] (values taken mod 256 like
+ * numpy's astype(uint8)), palette768 = the zero-padded 256 x 3 byte palette (:97-103), rgb f32 [B][3][HW],
+ * valid f32 [B][HW] or NULL. */
+int madm_label_to_rgb(const int64_t* label, const unsigned char* palette768, float* rgb, float* valid, int B, int HW,
+                      void* stream);
+/* pseudo labels (mtmadise.py:340-348): prob [B][HW] = max_k softmax(logits [B][K][HW]), label = first argmax (i64),
+ * *count_ge (u64, zeroed by the caller, NULL = skip) += number of pixels with prob >= threshold -- the reference's
+ * torch.sum(...).item() / size without the host sync. */
+int madm_pseudo_label(const float* logits, float* prob, int64_t* label, unsigned long long* count_ge, int B, int K, int HW,
+                      float threshold, void* stream);
+/* presence256[v] = 1 for every value v = label & 255 that occurs (the class list of torch.unique in
+ * utils/dacs_transforms.py:84 without the sort); presence256 zeroed by the caller. */
+int madm_label_presence(const int64_t* label, size_t n, unsigned* presence256, void* stream);
+/* ClassMix of ONE image pair (utils/dacs_transforms.py:92-111): mask = label0 in {v : chosen256[v]};
+ * out = mask * x0 + (1 - mask) * x1 for the C f32 planes [C][HW] and the i64 label plane; any of mask_out / img_out /
+ * label_out may be NULL. */
+int madm_class_mix(const int64_t* label0, const int64_t* label1, const unsigned char* chosen256, const float* img0,
+                   const float* img1, int C, int HW, float* mask_out, float* img_out, int64_t* label_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

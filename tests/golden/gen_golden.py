@@ -130,7 +130,31 @@ def main_slide():
     print(f"slide_s345: {time.time() - t0:.1f}s", {k: v.shape for k, v in out.items()})
 
 
+def main_labels():
+    """Label pipeline through the REFERENCE's own functions (extracted by AST from mtmadise.py / dacs_transforms.py,
+    oracle/labels.reference_functions): palette conversion, ClassMix masks with a seeded numpy RNG, one_mix; the
+    pseudo-label block (mtmadise.py:339-349) is plain torch and is restated in oracle/labels.pseudo_labels."""
+    from oracle import labels as L
+    from golden_util import LABEL_CASE, label_inputs
+    conv, gcm, _, mix = L.reference_functions()
+    inp = label_inputs(**LABEL_CASE)
+    pal768 = inp["palette"] + [0] * (768 - len(inp["palette"]))
+    rgb, valid = conv(inp["label"].clone(), pal768)
+    np.random.seed(LABEL_CASE["mix_seed"])
+    masks = gcm(inp["label"])
+    mixed_img, mixed_lbl = mix(masks[0], data=torch.stack((inp["imgs"][0], inp["imgs"][1])),
+                               target=torch.stack((inp["label"][0], inp["label"][1])))
+    prob, plabel, pweight = L.pseudo_labels(inp["logits"], (LABEL_CASE["H"], LABEL_CASE["W"]), LABEL_CASE["thr"])
+    out = dict(rgb=rgb.numpy(), valid=valid.numpy(), mask0=masks[0].numpy(), mask1=masks[1].numpy(),
+               mixed_img=mixed_img.numpy(), mixed_lbl=mixed_lbl.numpy(), prob=prob.numpy(), plabel=plabel.numpy(),
+               pweight=np.float32(pweight.flatten()[0].item()))
+    np.savez_compressed(os.path.join(HERE, "labels.npz"), **out)
+    print("labels.npz", {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    if "labels" in sys.argv[1:] or not sys.argv[1:]:
+        main_labels()
     if "slide_s345" in sys.argv[1:] or not sys.argv[1:]:
         main_slide()
     if not sys.argv[1:] or any(a in CASES for a in sys.argv[1:]):

@@ -78,3 +78,19 @@ def init_eval_params(backbone, head, seed=WEIGHT_SEED):
                         ("head.", head)):
         weights.synth_init_(mod, seed, prefix)
         weights.synth_buffers_(mod, seed, prefix)
+
+
+# ---- label / pseudo-label pipeline (tests/golden/labels.npz) ----
+LABEL_CASE = dict(B=2, K=19, H=48, W=80, thr=0.5, mix_seed=11)
+
+
+def label_inputs(B, K, H, W, **_):
+    """Seeded inputs of the label-pipeline tests: labels with ~8 % ignore pixels, a random K-colour palette, teacher
+    logits at quarter resolution, two image / label pairs for ClassMix."""
+    g = torch.Generator().manual_seed(4321)
+    lab = torch.randint(0, K, (B, 1, H, W), generator=g)
+    lab[torch.rand(lab.shape, generator=g) < 0.08] = 255
+    palette = [int(v) for v in torch.randint(0, 256, (K * 3,), generator=g)]
+    logits = 3.0 * torch.randn((B, K, H // 4, W // 4), generator=g)
+    imgs = torch.randn((B, 3, H, W), generator=g)
+    return {"label": lab, "palette": palette, "logits": logits, "imgs": imgs}

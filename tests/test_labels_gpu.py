@@ -1,0 +1,105 @@
+"""Label / pseudo-label pipeline on the device (csrc/labels.hip through madm_amd.labels) against the CPU oracle
+(oracle/labels.py) and the fixture generated from the reference's own functions (tests/golden/labels.npz).
+Index work is compared bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import LABEL_CASE, label_inputs
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "labels.npz")
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda")
+
+
+def test_convert_label_to_rgb_matches_reference_fixture(cuda):
+    from madm_amd import labels
+    inp = label_inputs(**LABEL_CASE)
+    gold = np.load(GOLD)
+    rgb, valid = labels.convert_label_to_rgb(inp["label"].cuda(), inp["palette"])
+    assert rgb.dtype == torch.float32 and tuple(rgb.shape) == gold["rgb"].shape
+    assert np.array_equal(rgb.cpu().numpy(), gold["rgb"])          # bit-exact, incl. the (x / 255 - 0.5) / 0.5 rounding
+    assert np.array_equal(valid.cpu().numpy(), gold["valid"])
+
+
+def test_convert_label_to_rgb_wraps_like_uint8_and_handles_all_256_entries(cuda):
+    from madm_amd import labels
+    from oracle import labels as L
+    g = torch.Generator().manual_seed(9)
+    lab = torch.randint(0, 1000, (1, 1, 17, 33), generator=g)      # astype(uint8) wraps
+    pal = [int(v) for v in torch.randint(0, 256, (768,), generator=g)]
+    rgb, valid = labels.convert_label_to_rgb(lab.cuda(), pal)
+    r0, v0 = L.convert_label_to_rgb(lab, pal)
+    assert torch.equal(rgb.cpu(), r0) and torch.equal(valid.cpu(), v0)
+
+
+def test_pseudo_labels(cuda):
+    from madm_amd import labels
+    from oracle import labels as L
+    inp = label_inputs(**LABEL_CASE)
+    gold = np.load(GOLD)
+    H, W, thr = LABEL_CASE["H"], LABEL_CASE["W"], LABEL_CASE["thr"]
+    prob, lab, weight = labels.pseudo_labels(inp["logits"].cuda(), (H, W), thr)
+    assert lab.dtype == torch.int64 and np.array_equal(lab.cpu().numpy(), gold["plabel"])       # argmax: bit-exact
+    assert np.abs(prob.cpu().numpy() - gold["prob"]).max() < 2e-6                              # f32 softmax
+    # the confident fraction may differ by the few pixels whose probability sits within rounding of the threshold
+    borderline = int((np.abs(gold["prob"] - thr) < 2e-6).sum())
+    n = gold["prob"].size
+    assert abs(float(weight.flatten()[0]) - float(gold["pweight"])) <= (borderline + 0.5) / n
+    assert tuple(weight.shape) == (LABEL_CASE["B"], H, W)
+    # ties: the FIRST maximum wins (torch.max / torch.argmax semantics)
+    x = torch.zeros((1, 5, 4, 4))
+    x[0, 3] = 1.0
+    x[0, 1] = 1.0
+    _, l2, _ = labels.pseudo_labels(x.cuda(), (4, 4), 0.9)
+    assert torch.equal(l2.cpu(), torch.full((1, 4, 4), 1, dtype=torch.int64))
+    p0, l0, _ = L.pseudo_labels(x, (4, 4), 0.9)
+    assert torch.equal(l0, l2.cpu())
+
+
+def test_class_mix_matches_reference_fixture(cuda):
+    from madm_amd import labels
+    inp = label_inputs(**LABEL_CASE)
+    gold = np.load(GOLD)
+    lab = inp["label"].cuda()
+    np.random.seed(LABEL_CASE["mix_seed"])
+    masks = labels.get_class_masks(lab)                    # same numpy RNG calls as the reference
+    assert np.array_equal(masks[0].cpu().numpy(), gold["mask0"].astype(np.float32))
+    assert np.array_equal(masks[1].cpu().numpy(), gold["mask1"].astype(np.float32))
+    # one_mix of pair (0, 1) under mask 0
+    classes = labels.label_classes(lab)
+    assert torch.equal(classes, torch.unique(inp["label"]))
+    chosen = torch.unique(inp["label"][0][torch.from_numpy(gold["mask0"][0]).bool()])
+    imgs = inp["imgs"].cuda()
+    m, mi, ml = labels.class_mix(lab[0], chosen, imgs[0], imgs[1], lab[1])
+    assert np.array_equal(mi.cpu().numpy()[None], gold["mixed_img"])
+    assert np.array_equal(ml.cpu().numpy()[None], gold["mixed_lbl"])
+
+
+def test_label_pipeline_full_size_properties(cuda):
+    """BASELINE size (2 x 512 x 512): all classes chosen -> first image, none -> second; a constant label map maps
+    to one colour; the palette conversion commutes with pixel permutation."""
+    from madm_amd import labels
+    g = torch.Generator().manual_seed(1)
+    lab = torch.randint(0, 19, (2, 1, 512, 512), generator=g).cuda()
+    imgs = torch.randn((2, 3, 512, 512), generator=g).cuda()
+    _, a, la = labels.class_mix(lab[0], torch.arange(19), imgs[0], imgs[1], lab[1])
+    _, b, lb = labels.class_mix(lab[0], torch.tensor([], dtype=torch.int64), imgs[0], imgs[1], lab[1])
+    assert torch.equal(a, imgs[0]) and torch.equal(la, lab[0]) and torch.equal(b, imgs[1]) and torch.equal(lb, lab[1])
+    pal = [int(v) for v in torch.randint(0, 256, (57,), generator=g)]
+    rgb, valid = labels.convert_label_to_rgb(lab, pal)
+    perm = torch.randperm(512 * 512, generator=g).cuda()
+    lab_p = lab.view(2, 1, -1)[:, :, perm].view(2, 1, 512, 512)
+    rgb_p, _ = labels.convert_label_to_rgb(lab_p, pal)
+    assert torch.equal(rgb_p.view(2, 3, -1), rgb.view(2, 3, -1)[:, :, perm]) and bool((valid == 1).all())
+    const, _ = labels.convert_label_to_rgb(torch.full((1, 1, 512, 512), 7, device="cuda"), pal)
+    want = (torch.tensor(pal[21:24], dtype=torch.uint8) / 255 - 0.5) / 0.5
+    assert torch.equal(const[0, :, 0, 0].cpu(), want) and bool((const == const[:, :, :1, :1]).all())
