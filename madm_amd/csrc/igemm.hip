@@ -12,6 +12,79 @@
 
 namespace {
 
+// ---- tile epilogue shared by the register-staged and the LDS-DMA kernels ----------------------------------------
+// lane holds pixel m (lane & 15), channels n .. n+3 (4 * (lane >> 4)) of each 16x16 sub-tile.
+// Optional fused GroupNorm statistics of the OUTPUT tensor: per-(image, channel) sum and sum of squares accumulated
+// in the f64 stats[B][N][2] (f32 partials per block, f64 atomics across blocks: reproducible to f32 rounding whatever
+// the arrival order) -- the consumer GroupNorm then needs no pass of its own.  ``red`` = >= 4 * BN floats of LDS that
+// no wave reads any more (the caller has passed a barrier since the last MFMA operand read).
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0,
+                                                    int z, float* red) {
+    constexpr int MI = BM / 32, NI = BN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int OHW = p.OH * p.OW;
+    const bool want_stats = p.stats != nullptr && p.splitk == 1;
+    int mlast = m0 + BM; if (mlast > p.M) mlast = p.M; mlast -= 1;
+    const int img0 = m0 / OHW;
+    const bool one_image = (mlast / OHW) == img0;   // block-uniform
+    const int nb = n0 + wn * (BN / 2) + fg * 4;
+    f32x4 cs[NI], cq[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + frow;
+        if (m >= p.M) continue;
+        if (p.splitk > 1) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const f32x4 v = acc[i][j];
+                if (nb + 16 * j < p.N)
+                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + nb + 16 * j) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            epilogue_row<T, NI>(p, m, nb, acc[i]);
+            if (want_stats) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if (nb + 16 * j >= p.N) continue;
+                    if (one_image) { cs[j] += acc[i][j]; cq[j] += acc[i][j] * acc[i][j]; }
+                    else stats_add_elementwise(p, m, nb + 16 * j, acc[i][j]);
+                }
+            }
+        }
+    }
+    if (want_stats && one_image) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cs[j][r] += __shfl_xor(cs[j][r], o);
+                    cq[j][r] += __shfl_xor(cq[j][r], o);
+                }
+            }
+            if (frow == 0) {
+                float* dst = red + ((wm * BN) + wn * (BN / 2) + j * 16 + fg * 4) * 2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { dst[2 * r] = cs[j][r]; dst[2 * r + 1] = cq[j][r]; }
+            }
+        }
+    }
+    if (want_stats && one_image) {
+        __syncthreads();
+        for (int c = tid; c < 2 * BN; c += 256) {   // c = channel * 2 + {sum, sumsq}
+            const int n = n0 + (c >> 1);
+            if (n < p.N) atomicAdd(p.stats + ((size_t)img0 * p.N + n0) * 2 + c, (double)red[c] + (double)red[2 * BN + c]);
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int NST>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_kernel(const IgemmP p) {
     constexpr int EPC = TT<T>::EPC;
@@ -161,68 +234,186 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
 #undef IGEMM_LOAD_TILE
 #undef IGEMM_STORE_TILE
 
-    // ---- epilogue: lane holds pixel m (lane & 15), channels n .. n+3 (4 * (lane >> 4)) ----
-    // Optional fused GroupNorm statistics of the OUTPUT tensor: per-(image, channel) sum and sum of
-    // squares accumulated in the f64 stats[B][N][2] (f32 partials per block, f64 atomics across blocks: the
-    // result is reproducible to f32 rounding whatever the arrival order) -- the consumer GroupNorm then needs no pass of its own.
-    const bool want_stats = p.stats != nullptr && p.splitk == 1;
-    int mlast = m0 + BM; if (mlast > p.M) mlast = p.M; mlast -= 1;
-    const int img0 = m0 / OHW;
-    const bool one_image = (mlast / OHW) == img0;   // block-uniform
-    float* red = reinterpret_cast<float*>(smem);     // [2 (wm)][BN][2], reuses the staging LDS
-    const int nb = n0 + wn * (BN / 2) + fg * 4;
-    f32x4 cs[NI], cq[NI];
+    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(smem));
+}
+
+// ---- LDS-DMA variant ----------------------------------------------------------------------------------------------
+// Same GEMM view, tiles and LDS image as igemm_kernel, but both operand tiles travel global -> LDS directly
+// (`buffer_load_dwordx4 ... lds`: each wave instruction lands 8 rows x 128 B at M0 + lane * 16): no staging registers,
+// no ds_write phase, NS - 1 K-tiles in flight per block.  The XOR swizzle is applied on the SOURCE side (lane (r, p)
+// fetches global chunk p ^ (r & 7)), so the LDS image -- and the fragment reads -- are those of igemm_kernel.
+// Per K-tile: counted s_waitcnt vmcnt (only this tile's loads must have landed) -> one barrier (tile visible to every
+// wave, previous slot free) -> issue the loads of tile t + NS - 1 into that slot -> ds_read + MFMA.
+#define GLDS_ASM(...) asm volatile(__VA_ARGS__)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int N> __device__ __forceinline__ void wait_vmcnt() { GLDS_ASM("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { GLDS_ASM("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+#endif
+
+template <typename T, int BM, int BN, int NS>
+__global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const IgemmP p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // LDS address-space casts and gfx asm: device pass only (the host needs the stub)
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int BKE = 8 * EPC;
+    constexpr int MI = BM / 32, NI = BN / 32;
+    constexpr int ROWS = BM + BN;
+    constexpr int LPT = ROWS / 32;          // wave instructions (8 rows each) per wave and K-tile
+    constexpr int TILE_U4 = ROWS * 8;
+    static_assert(NS >= 3 && NS <= 4 && ROWS % 32 == 0, "ring depth / tile shape");
+    extern __shared__ __attribute__((aligned(16))) uint4 gsmem[];   // [NS][ROWS][8 x 16 B]
+    typedef __attribute__((address_space(3))) char lds_char;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;   // XCD-aware order, see igemm_kernel
+    {
+        const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int tn = bid % p.tilesN, tm = bid / p.tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const int rsub = lane >> 3, cpos = lane & 7;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const int OHW = p.OH * p.OW;
+    // per wave instruction i: rows 8 * (wave * LPT + i) .. + 7 of the stacked [A | W] tile
+    int a_b[LPT], a_iy[LPT], a_ix[LPT];
+    unsigned wvoff[LPT], swz[LPT];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + frow;
-        if (m >= p.M) continue;
-        if (p.splitk > 1) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const f32x4 v = acc[i][j];
-                if (nb + 16 * j < p.N)
-                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + nb + 16 * j) =
-                        make_float4(v[0], v[1], v[2], v[3]);
+    for (int i = 0; i < LPT; ++i) {
+        const int row = (wave * LPT + i) * 8 + rsub;
+        swz[i] = (unsigned)((cpos ^ (row & 7)) * EPC);
+        a_b[i] = 0; a_iy[i] = -(1 << 24); a_ix[i] = 0; wvoff[i] = OOB;
+        if (row < BM) {
+            const int m = m0 + row;
+            if (m < p.M) {
+                const int b = m / OHW;
+                const int r = m - b * OHW;
+                const int oy = r / p.OW;
+                const int ox = r - oy * p.OW;
+                a_b[i] = b * p.IH; a_iy[i] = oy * p.stride - p.pad_t; a_ix[i] = ox * p.stride - p.pad_l;
             }
         } else {
-            epilogue_row<T, NI>(p, m, nb, acc[i]);
-            if (want_stats) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if (nb + 16 * j >= p.N) continue;
-                    if (one_image) { cs[j] += acc[i][j]; cq[j] += acc[i][j] * acc[i][j]; }
-                    else stats_add_elementwise(p, m, nb + 16 * j, acc[i][j]);
-                }
-            }
+            const int n = n0 + row - BM;
+            if (n < p.N) wvoff[i] = (unsigned)(((size_t)n * p.ldw + swz[i]) * sizeof(T));
         }
     }
-    if (want_stats && one_image) {
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.bytes1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in2 ? p.in2 : p.in1), 0,
+                                                                         p.in2 ? p.bytes2 : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.bytesw, 0x00020000);
+
+    const int kt0 = (int)(((long long)p.nk * z) / p.splitk);
+    const int kt1 = (int)(((long long)p.nk * (z + 1)) / p.splitk);
+    const int nt = kt1 - kt0;
+    int c0, tr, ts;   // tap state of the NEXT tile to load
+    {
+        const int kbase = kt0 * BKE;
+        const int tap = kbase / p.Ctot;
+        c0 = kbase - tap * p.Ctot;
+        tr = tap / p.KW;
+        ts = tap - tr * p.KW;
+    }
+    const int IHe = p.upsample ? 2 * p.IH : p.IH;
+    const int IWe = p.upsample ? 2 * p.IW : p.IW;
+    const int ush = p.upsample ? 1 : 0;
+    lds_char* const lds0 = (lds_char*)gsmem;
+
+#define GLDS_LOAD_TILE(kt, slot)                                                                                 \
+    {                                                                                                            \
+        const bool first = c0 < p.C1;                                                                            \
+        const __amdgpu_buffer_rsrc_t rs = first ? rs1 : rs2;                                                     \
+        const int ld = first ? p.ld1 : p.ld2;                                                                    \
+        const int cbase = first ? c0 : c0 - p.C1;                                                                \
+        const unsigned kofs = (unsigned)(kt) * (unsigned)(BKE * sizeof(T));                                      \
+        _Pragma("unroll") for (int i = 0; i < LPT; ++i) {                                                        \
+            const int q = wave * LPT + i;                                                                        \
+            lds_char* dst = lds0 + ((slot) * TILE_U4 + q * 64) * 16;                                             \
+            if (q * 8 < BM) {   /* wave-uniform */                                                               \
+                const int iy = a_iy[i] + tr, ix = a_ix[i] + ts;                                                  \
+                const bool ok = (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;                    \
+                const unsigned off = (unsigned)(((a_b[i] + (iy >> ush)) * p.IW + (ix >> ush)) * ld + cbase +     \
+                                                (int)swz[i]) * (unsigned)sizeof(T);                              \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, ok ? off : OOB, 0, 0, 0);                  \
+            } else {                                                                                             \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff[i], kofs, 0, 0);                    \
+            }                                                                                                    \
+        }                                                                                                        \
+        c0 += BKE;                                                                                               \
+        if (c0 >= p.Ctot) { c0 = 0; ++ts; if (ts == p.KW) { ts = 0; ++tr; } }                                    \
+    }
+
+    f32x4 acc[MI][NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    cs[j][r] += __shfl_xor(cs[j][r], o);
-                    cq[j][r] += __shfl_xor(cq[j][r], o);
-                }
-            }
-            if (frow == 0) {
-                float* dst = red + ((wm * BN) + wn * (BN / 2) + j * 16 + fg * 4) * 2;
+    for (int u = 0; u < NS - 1; ++u)
+        if (u < nt) GLDS_LOAD_TILE(kt0 + u, u);
+
+    const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
+    unsigned aA[2], aB[2];   // LDS byte addresses of this lane's fragment chunk in slot 0 (rows + i * 16 via offset:)
+    {
+        const unsigned base = (unsigned)(size_t)lds0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { dst[2 * r] = cs[j][r]; dst[2 * r + 1] = cq[j][r]; }
-            }
+        for (int kk = 0; kk < 2; ++kk) {
+            const int c = (fg + 4 * kk) ^ fsw;
+            aA[kk] = base + (unsigned)(((wm * (BM / 2) + frow) * 8 + c) * 16);
+            aB[kk] = base + (unsigned)(((BM + wn * (BN / 2) + frow) * 8 + c) * 16);
         }
     }
-    if (want_stats && one_image) {
-        __syncthreads();
-        for (int c = tid; c < 2 * BN; c += 256) {   // c = channel * 2 + {sum, sumsq}
-            const int n = n0 + (c >> 1);
-            if (n < p.N) atomicAdd(p.stats + ((size_t)img0 * p.N + n0) * 2 + c, (double)red[c] + (double)red[2 * BN + c]);
-        }
+    // one K-tile; CUR / NXT are compile-time slots (the loop is unrolled by NS) so the compiler can tell the slot being
+    // read from the slots the in-flight DMA writes, and does not drain vmcnt before the ds_reads
+#define GLDS_STEP(t, CUR, NXT)                                                                                   \
+    {                                                                                                            \
+        const int ahead = (nt - 1 - (t) < NS - 2) ? nt - 1 - (t) : NS - 2;   /* tiles issued after tile t */       \
+        if (ahead >= 2) wait_vmcnt<2 * LPT>();                                                                   \
+        else if (ahead == 1) wait_vmcnt<LPT>();                                                                  \
+        else wait_vmcnt<0>();                                                                                    \
+        __builtin_amdgcn_s_barrier();   /* tile t landed for every wave; slot NXT (tile t - 1) is free */        \
+        if ((t) + NS - 1 < nt) GLDS_LOAD_TILE(kt0 + (t) + NS - 1, NXT);                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        {                                                                                                        \
+            /* fragment reads as inline asm: the compiler drains vmcnt(0) before any ds_read it can see while   \
+               LDS-DMA is in flight (it cannot tell the slots apart), which would serialise the ring */         \
+            u32x4 af[2][MI], wf[2][NI];                                                                          \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                   \
+                const unsigned pa = aA[kk] + (CUR) * (TILE_U4 * 16), pb = aB[kk] + (CUR) * (TILE_U4 * 16);       \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                   \
+                    GLDS_ASM("ds_read_b128 %0, %1 offset:%2" : "=v"(af[kk][i]) : "v"(pa), "n"(i * 2048));         \
+                _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
+                    GLDS_ASM("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[kk][j]) : "v"(pb), "n"(j * 2048));         \
+            }                                                                                                    \
+            wait_lgkmcnt<MI + NI>();                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
+                    mma16<T>(__builtin_bit_cast(uint4, wf[0][j]), __builtin_bit_cast(uint4, af[0][i]), acc[i][j]); \
+            wait_lgkmcnt<0>();                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
+                _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
+                    mma16<T>(__builtin_bit_cast(uint4, wf[1][j]), __builtin_bit_cast(uint4, af[1][i]), acc[i][j]); \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
     }
+    int t = 0;
+    for (; t + NS <= nt; t += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) GLDS_STEP(t + u, u, (u + NS - 1) % NS);
+    }
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (t + u < nt) GLDS_STEP(t + u, u, (u + NS - 1) % NS);
+#undef GLDS_STEP
+#undef GLDS_LOAD_TILE
+    __syncthreads();   // every wave is done with the last tile: the LDS becomes the statistics scratch
+    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(gsmem));
+#endif
 }
 
 // sums the split-K slabs and applies the epilogue (+ the fused GroupNorm statistics).
@@ -279,7 +470,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
 }
 
 int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
-inline bool is_igemm_tile(int t) { return t <= 3 || t == 6; }
+inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8); }
 inline bool is_halo_tile(int t) { return t == 4 || t == 5; }
 
 // Launch configurations measured on MI355X by tools/tune_insitu.py for the layer shapes of the SD-v1-4
@@ -313,7 +504,8 @@ bool halo_eligible(const madm_conv2d_args* a) {
 }
 
 // tile codes: 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 BN=128, 5 = halo BN=64,
-// 6 = igemm 64x64 with an 8-deep register prefetch (latency-bound small-M GEMMs streaming cold weights)
+// 6 = igemm 64x64 with an 8-deep register prefetch (latency-bound small-M GEMMs streaming cold weights),
+// 7 / 8 = LDS-DMA igemm 64x64 (4-slot ring) / 128x64 (3-slot ring)
 int pick_tile(const madm_conv2d_args* a) {
     const int M = a->B * a->OH * a->OW, K = a->KH * a->KW * (a->C1 + a->C2);
     const bool halo_ok = halo_eligible(a);
@@ -333,7 +525,7 @@ int pick_tile(const madm_conv2d_args* a) {
 
 void tile_dims(int t, int& bm, int& bn) {
     if (t == 1 || t == 4) { bm = 128; bn = 128; }
-    else if (t == 2 || t == 5) { bm = 128; bn = 64; }
+    else if (t == 2 || t == 5 || t == 8) { bm = 128; bn = 64; }
     else { bm = 64; bn = 64; }
 }
 
@@ -391,6 +583,26 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     return MADM_OK;
 }
 
+template <typename T, int BM, int BN, int NS>
+int launch_glds(const IgemmP& p, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
+    auto kern = igemm_glds_kernel<T, BM, BN, NS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                madm_set_error("igemm (LDS-DMA): cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
+                return MADM_ERR_LAUNCH;
+            }
+        }
+        attr_set = true;
+    }
+    kern<<<grid, 256, lds, s>>>(p);
+    return MADM_OK;
+}
+
 template <typename T>
 int launch(const IgemmP& p0, int t, hipStream_t s) {
     IgemmP p = p0;
@@ -406,6 +618,8 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
         if (t == 1) igemm_kernel<T, 128, 128, 2><<<grid, 256, 0, s>>>(p);
         else if (t == 2) igemm_kernel<T, 128, 64, 3><<<grid, 256, 0, s>>>(p);
         else if (t == 6) igemm_kernel<T, 64, 64, 8><<<grid, 256, 0, s>>>(p);
+        else if (t == 7) { if (int e = launch_glds<T, 64, 64, 4>(p, grid, s)) return e; }
+        else if (t == 8) { if (int e = launch_glds<T, 128, 64, 3>(p, grid, s)) return e; }
         else igemm_kernel<T, 64, 64, 4><<<grid, 256, 0, s>>>(p);
         rc = madm_check_launch("igemm_kernel");
     }

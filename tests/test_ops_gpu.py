@@ -49,6 +49,19 @@ CONV_CASES = [
     # 6 = igemm 64x64 with the 8-deep prefetch ring (K long enough to wrap it, and a split K shorter than it)
     ("deep_igemm64", 2, [640], 8, 8, 320, 1, 1, "same", False, 6, 1),
     ("deep_igemm64_splitk", 2, [1280], 4, 4, 128, 3, 1, "same", False, 6, 3),
+    # 7 / 8 = LDS-DMA igemm (buffer_load ... lds, 4- / 3-slot ring): padding rows must land as zeros, ragged M / N,
+    # K shorter and longer than the ring, concat, stride 2, upsample, split-K
+    ("glds64_3x3", 2, [64], 8, 8, 64, 3, 1, "same", False, 7, 1),
+    ("glds64_ragged", 2, [64], 5, 7, 320, 3, 1, "same", False, 7, 1),
+    ("glds64_1x1_longk", 2, [1280], 8, 8, 320, 1, 1, "none", False, 7, 1),
+    ("glds64_1x1_onetile", 2, [64], 8, 8, 64, 1, 1, "none", False, 7, 1),
+    ("glds64_concat_s2", 2, [128, 64], 16, 16, 192, 3, 2, "same", False, 7, 1),
+    ("glds64_upsample", 2, [64], 6, 6, 64, 3, 1, "same", True, 7, 1),
+    ("glds64_splitk", 2, [256], 4, 4, 128, 3, 1, "same", False, 7, 4),
+    ("glds128_3x3", 1, [64], 12, 20, 320, 3, 1, "same", False, 8, 1),
+    ("glds128_asym_s2", 2, [64], 16, 16, 128, 3, 2, "asym", False, 8, 1),
+    ("glds128_1x1_longk_splitk", 2, [640], 8, 8, 640, 1, 1, "none", False, 8, 2),
+    ("glds128_tiny_cout", 2, [64], 8, 8, 4, 3, 1, "same", False, 8, 1),
 ]
 
 

@@ -27,7 +27,7 @@ def rows_of(path):
         if key in seen:
             continue
         seen.add(key)
-        tile = {7: 5, 8: 4}.get(int(m.group(6)), int(m.group(6)))   # retired experimental variants
+        tile = int(m.group(6))
         out.append(key + (tile, int(m.group(7))))
     return sorted(out)
 
