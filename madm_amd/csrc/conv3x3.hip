@@ -11,24 +11,9 @@
 //   pipeline: weights run two taps ahead in registers (as igemm.hip), the next chunk's halo is loaded at
 //   tap 0 and written to the other halo buffer after tap 8; one barrier per tap.
 // Epilogue (bias, time row, residual, GroupNorm sums of the output, split-K slabs) is shared with igemm.hip.
-#include "igemm_common.hpp"
+#include "conv3x3_common.hpp"
 
 namespace {
-
-constexpr int TH = 8, TW = 16, HWD = TW + 2, HPIX = (TH + 2) * HWD;  // 180 halo pixels
-#ifdef C3_STAMPS
-__device__ unsigned long long g_c3_stamps[2048];
-#endif
-
-template <typename T, int EPC>
-__device__ __forceinline__ u32x4 gn_act_chunk(u32x4 raw, const float* sc, const float* sh, int act) {
-    float f[EPC];
-    chunk_to_f32<T>(__builtin_bit_cast(uint4, raw), f);
-#pragma unroll
-    for (int j = 0; j < EPC; ++j) f[j] = f[j] * sc[j] + sh[j];
-    act_inplace<EPC>(f, act);
-    return __builtin_bit_cast(u32x4, f32_to_chunk<T>(f));
-}
 
 template <typename T, int BN, bool FUSE, int NWS>
 __global__ __launch_bounds__(256, (NWS == 2 || BN == 64) ? 2 : 1) void conv3x3_halo_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
@@ -262,61 +247,7 @@ __global__ __launch_bounds__(256, (NWS == 2 || BN == 64) ? 2 : 1) void conv3x3_h
 #undef C3_LOAD_HALO
 #undef C3_STORE_HALO
 
-    // ---- epilogue (lane: pixel = patch row wm*4+i, column frow; channels n .. n+3) ----
-    const bool want_stats = p.stats != nullptr && p.splitk == 1;
-    float* red = reinterpret_cast<float*>(smem_raw);   // [2 (wm)][BN][2]
-    const int nb = n0 + wn * (BN / 2) + fg * 4;
-    f32x4 cs[NI], cq[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int oy = py0 + wm * 4 + i, ox = px0 + frow;
-        if (oy >= p.OH || ox >= p.OW) continue;
-        const int m = (b * p.OH + oy) * p.OW + ox;
-        if (p.splitk > 1) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const f32x4 v = acc[i][j];
-                if (nb + 16 * j < p.N)
-                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + nb + 16 * j) =
-                        make_float4(v[0], v[1], v[2], v[3]);
-            }
-        } else {
-            epilogue_row<T, NI>(p, m, nb, acc[i]);
-            if (want_stats) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    if (nb + 16 * j < p.N) { cs[j] += acc[i][j]; cq[j] += acc[i][j] * acc[i][j]; }
-            }
-        }
-    }
-    if (want_stats) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    cs[j][r] += __shfl_xor(cs[j][r], o);
-                    cq[j][r] += __shfl_xor(cq[j][r], o);
-                }
-            }
-            if (frow == 0) {
-                float* dst = red + ((wm * BN) + wn * (BN / 2) + j * 16 + fg * 4) * 2;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { dst[2 * r] = cs[j][r]; dst[2 * r + 1] = cq[j][r]; }
-            }
-        }
-    }
-    if (want_stats) {
-        __syncthreads();
-        for (int c = tid; c < 2 * BN; c += 256) {
-            const int n = n0 + (c >> 1);
-            if (n < p.N)
-                atomicAdd(p.stats + ((size_t)b * p.N + n0) * 2 + c, (double)red[c] + (double)red[2 * BN + c]);
-        }
-    }
+    halo_tile_epilogue<T, BN>(p, acc, b, py0, px0, n0, z, reinterpret_cast<float*>(smem_raw));
 }
 
 template <typename T, int BN, bool FUSE, int NWS>

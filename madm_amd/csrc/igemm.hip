@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
 
 int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
 inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8); }
-inline bool is_halo_tile(int t) { return t == 4 || t == 5; }
+inline bool is_halo_tile(int t) { return t == 4 || t == 5 || t == 9 || t == 10; }
 
 // Launch configurations measured on MI355X by tools/tune_insitu.py for the layer shapes of the SD-v1-4
 // feature extractor at bs=2, 512x512 (any other shape falls back to the heuristics below).
@@ -505,7 +505,7 @@ bool halo_eligible(const madm_conv2d_args* a) {
 
 // tile codes: 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 BN=128, 5 = halo BN=64,
 // 6 = igemm 64x64 with an 8-deep register prefetch (latency-bound small-M GEMMs streaming cold weights),
-// 7 / 8 = LDS-DMA igemm 64x64 (4-slot ring) / 128x64 (3-slot ring)
+// 7 / 8 = LDS-DMA igemm 64x64 (4-slot ring) / 128x64 (3-slot ring), 9 / 10 = halo BN=128 / BN=64 with LDS-DMA weights
 int pick_tile(const madm_conv2d_args* a) {
     const int M = a->B * a->OH * a->OW, K = a->KH * a->KW * (a->C1 + a->C2);
     const bool halo_ok = halo_eligible(a);
@@ -524,8 +524,8 @@ int pick_tile(const madm_conv2d_args* a) {
 }
 
 void tile_dims(int t, int& bm, int& bn) {
-    if (t == 1 || t == 4) { bm = 128; bn = 128; }
-    else if (t == 2 || t == 5 || t == 8) { bm = 128; bn = 64; }
+    if (t == 1 || t == 4 || t == 9) { bm = 128; bn = 128; }
+    else if (t == 2 || t == 5 || t == 8 || t == 10) { bm = 128; bn = 64; }
     else { bm = 64; bn = 64; }
 }
 
@@ -610,7 +610,7 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
     tile_dims(t, bm, bn);
     int rc;
     if (is_halo_tile(t)) {
-        rc = launch_conv3x3_halo<T>(p, bn, s);
+        rc = (t >= 9) ? launch_conv3x3_halo_dma<T>(p, bn, s) : launch_conv3x3_halo<T>(p, bn, s);
     } else {
         p.tilesN = (p.N + bn - 1) / bn;
         const int tilesM = (p.M + bm - 1) / bm;

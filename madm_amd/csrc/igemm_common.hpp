@@ -164,3 +164,5 @@ __device__ __forceinline__ void stats_add_elementwise(const IgemmP& p, int m, in
 
 // conv3x3.hip: stride-1 / pad-1 3x3 conv with the input staged as an LDS halo tile (bn = 128 or 64)
 template <typename T> int launch_conv3x3_halo(const IgemmP& p, int bn, hipStream_t s);
+// conv3x3_dma.hip: the same with the weight tiles moved by LDS-DMA (three-slot ring, single halo buffer)
+template <typename T> int launch_conv3x3_halo_dma(const IgemmP& p, int bn, hipStream_t s);

@@ -62,6 +62,13 @@ CONV_CASES = [
     ("glds128_asym_s2", 2, [64], 16, 16, 128, 3, 2, "asym", False, 8, 1),
     ("glds128_1x1_longk_splitk", 2, [640], 8, 8, 640, 1, 1, "none", False, 8, 2),
     ("glds128_tiny_cout", 2, [64], 8, 8, 4, 3, 1, "same", False, 8, 1),
+    # 9 / 10 = halo conv with LDS-DMA weights (three-slot ring, single halo buffer)
+    ("halodma128", 2, [128], 16, 32, 256, 3, 1, "same", False, 9, 1),
+    ("halodma64", 2, [64], 16, 16, 320, 3, 1, "same", False, 10, 1),
+    ("halodma_ragged", 1, [64], 13, 21, 192, 3, 1, "same", False, 9, 1),
+    ("halodma_concat", 2, [128, 64], 8, 16, 128, 3, 1, "same", False, 10, 1),
+    ("halodma_splitk", 2, [256], 8, 16, 64, 3, 1, "same", False, 10, 2),
+    ("halodma_longk", 2, [640], 8, 16, 128, 3, 1, "same", False, 9, 1),
 ]
 
 
@@ -199,8 +206,11 @@ def test_conv_fused_groupnorm_stats(cuda, dtype, case):
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [(2, [128], 16, 32, 128, True, 4), (2, [320], 16, 16, 320, True, 5),
                                   (1, [64], 11, 19, 64, False, 5), (2, [128, 64], 8, 16, 192, True, 5),
-                                  (2, [1280, 640], 8, 16, 64, True, 5)],
-                         ids=["x128", "x64", "ragged_affine", "concat", "concat_straddle"])
+                                  (2, [1280, 640], 8, 16, 64, True, 5), (2, [128], 16, 32, 128, True, 9),
+                                  (2, [320], 16, 16, 320, True, 10), (2, [1280, 640], 8, 16, 64, True, 10),
+                                  (1, [64], 11, 19, 64, False, 9)],
+                         ids=["x128", "x64", "ragged_affine", "concat", "concat_straddle", "dma128", "dma64",
+                              "dma_concat_straddle", "dma_ragged_affine"])
 def test_conv_fused_groupnorm_input(cuda, dtype, case):
     """conv3x3(silu(GroupNorm([x | skip]))) with the normalisation folded into the conv's LDS halo load
     (channel sums -> group mean / rstd in the conv's own prologue) equals the unfused torch composition,

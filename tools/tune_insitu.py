@@ -17,7 +17,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 TILE_OF = {"igemm_128x128": 1, "igemm_128x64": 2, "igemm_64x64": 3, "conv3x3_halo_x128": 4, "conv3x3_halo_x64": 5,
-           "igemm_64x64d": 6, "igemm_glds_64x64": 7, "igemm_glds_128x64": 8}
+           "igemm_64x64d": 6, "igemm_glds_64x64": 7, "igemm_glds_128x64": 8,
+           "conv3x3_halo_dma_x128": 9, "conv3x3_halo_dma_x64": 10}
 
 
 def main():
@@ -27,7 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--workload", default="extract", choices=["extract", "eval"])
-    ap.add_argument("--tiles", type=int, nargs="*", default=[1, 2, 3, 4, 5, 6, 7, 8])
+    ap.add_argument("--tiles", type=int, nargs="*", default=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
     ap.add_argument("--splitk", type=int, nargs="*", default=[1, 2, 3, 4, 6, 8, 12, 16, 24])
     args = ap.parse_args()
     from madm_amd.ldm_rocm import LdmRocm
@@ -66,7 +67,7 @@ def main():
                 rec = profiled()
                 assert len(rec) == n
                 for i, (name, desc, us) in enumerate(rec):
-                    t = TILE_OF[name.rsplit("_", 1)[0]]
+                    t = TILE_OF[name.rsplit("_", 1)[0]]   # strip the dtype suffix
                     s = int(re.search(r"sk(\d+)", desc).group(1))
                     results[i][(t, s)].append(us)
         finally:
