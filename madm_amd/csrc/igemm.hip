@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
 // Per K-tile: counted s_waitcnt vmcnt (only this tile's loads must have landed) -> one barrier (tile visible to every
 // wave, previous slot free) -> issue the loads of tile t + NS - 1 into that slot -> ds_read + MFMA.
 #define GLDS_ASM(...) asm volatile(__VA_ARGS__)
+#ifdef GLDS_STAMPS
+__device__ unsigned long long g_glds_stamps[2048];
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int N> __device__ __forceinline__ void wait_vmcnt() { GLDS_ASM("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() { GLDS_ASM("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
@@ -366,15 +369,28 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const IgemmP p) {
             aB[kk] = base + (unsigned)(((BM + wn * (BN / 2) + frow) * 8 + c) * 16);
         }
     }
+    // Measured and rejected (MI355X, in-kernel stamps tools/exp/stamps_glds.py): the 4 DMA instructions of a 64x64 tile
+    // cost ~550 of the ~1250 clocks of a K-step (the CU's load path moves 64 B/clk and both resident blocks issue right
+    // after their barrier); issuing them between groups of MFMAs did not hide that (+9 % time), and a 128x128 tile
+    // (one block per CU) was 1.5x slower than the register-staged 128x64 kernel.
     // one K-tile; CUR / NXT are compile-time slots (the loop is unrolled by NS) so the compiler can tell the slot being
     // read from the slots the in-flight DMA writes, and does not drain vmcnt before the ds_reads
+#ifdef GLDS_STAMPS   // tools/exp: shader-clock stamps of block 0 / wave 0 (step start, DMA landed, barrier passed, MFMAs issued)
+#define GLDS_STAMP(t_, k_)                                                                                       \
+    if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0 && (t_) < 500) g_glds_stamps[(t_) * 4 + (k_)] = __builtin_readcyclecounter();
+#else
+#define GLDS_STAMP(t_, k_)
+#endif
 #define GLDS_STEP(t, CUR, NXT)                                                                                   \
     {                                                                                                            \
         const int ahead = (nt - 1 - (t) < NS - 2) ? nt - 1 - (t) : NS - 2;   /* tiles issued after tile t */       \
+        GLDS_STAMP(t, 0);                                                                                        \
         if (ahead >= 2) wait_vmcnt<2 * LPT>();                                                                   \
         else if (ahead == 1) wait_vmcnt<LPT>();                                                                  \
         else wait_vmcnt<0>();                                                                                    \
+        GLDS_STAMP(t, 1);                                                                                        \
         __builtin_amdgcn_s_barrier();   /* tile t landed for every wave; slot NXT (tile t - 1) is free */        \
+        GLDS_STAMP(t, 2);                                                                                        \
         if ((t) + NS - 1 < nt) GLDS_LOAD_TILE(kt0 + (t) + NS - 1, NXT);                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
         {                                                                                                        \
@@ -400,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const IgemmP p) {
                     mma16<T>(__builtin_bit_cast(uint4, wf[1][j]), __builtin_bit_cast(uint4, af[1][i]), acc[i][j]); \
         }                                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
+        GLDS_STAMP(t, 3);                                                                                        \
     }
     int t = 0;
     for (; t + NS <= nt; t += NS) {
@@ -635,6 +652,12 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
 }  // namespace
 
 extern "C" {
+
+#ifdef GLDS_STAMPS
+int madm_debug_read_glds_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_glds_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 void madm_debug_set_conv_tile(int t) { g_tile_override = t; }
 
