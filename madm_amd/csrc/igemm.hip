@@ -8,6 +8,7 @@
 // t+1 are issued before the MFMAs of tile t and written to the other buffer after them; one
 // barrier per K-tile.  The MFMA is issued as D = W_frag x A_frag so that every lane ends up with
 // 4 CONSECUTIVE output channels of one pixel: 8/16-byte stores, vector bias / residual loads.
+#include <cstdlib>
 #include "igemm_common.hpp"
 
 namespace {
@@ -514,10 +515,17 @@ int heuristic_tile(int M, int N) {
     return 3;
 }
 
+// narrowest map the halo kernels take (env MADM_HALO_MIN_W for A/B runs; ops.can_fuse_groupnorm mirrors it): an 8-wide
+// map wastes half of every 8 x 16 patch, but lets the 8 x 8 UNet level fuse its GroupNorm
+int halo_min_width() {
+    static const int w = [] { const char* e = getenv("MADM_HALO_MIN_W"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
+    return w;
+}
+
 // the LDS halo-tile kernel (conv3x3.hip) handles 3x3 / stride 1 / pad 1 convs on maps of at least one patch
 bool halo_eligible(const madm_conv2d_args* a) {
     return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && !a->upsample &&
-           a->OH == a->IH && a->OW == a->IW && a->OH >= 8 && a->OW >= 16 && a->epilogue != MADM_EPI_GEGLU;
+           a->OH == a->IH && a->OW == a->IW && a->OH >= 8 && a->OW >= halo_min_width() && a->epilogue != MADM_EPI_GEGLU;
 }
 
 // tile codes: 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 BN=128, 5 = halo BN=64,

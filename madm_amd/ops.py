@@ -51,6 +51,7 @@ _TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64", 4: "conv
                10: "conv3x3_halo_dma_x64"}
 FORCE_SPLITK = None   # tools/tune_insitu.py: split-K factor forced on every small-M launch
 FUSE_GN = True   # fold GroupNorm(+SiLU) into eligible 3x3 convs (debug switch)
+HALO_MIN_W = int(__import__("os").environ.get("MADM_HALO_MIN_W", "8"))   # mirrors halo_min_width() of igemm.hip
 import os as _os
 FUSE_GN_MAX_N = int(_os.environ.get("MADM_FUSE_GN_MAX_N", "1000000"))   # ... of any width: with the rcp-based SiLU the
 # transform redone per output tile costs less than a stand-alone GroupNorm pass + launch (same-box A/B: 128 -> 192.9,
@@ -59,7 +60,8 @@ FUSE_GN_MAX_N = int(_os.environ.get("MADM_FUSE_GN_MAX_N", "1000000"))   # ... of
 
 def can_fuse_groupnorm(IH, IW, KH, stride, pad, asym_pad, upsample):
     """Mirror of madm_conv2d_can_fuse_groupnorm (the LDS halo-tile 3x3 kernel applies)."""
-    return FUSE_GN and KH == 3 and stride == 1 and pad == 1 and not asym_pad and not upsample and IH >= 8 and IW >= 16
+    return (FUSE_GN and KH == 3 and stride == 1 and pad == 1 and not asym_pad and not upsample and IH >= 8
+            and IW >= HALO_MIN_W)
 
 
 def groupnorm_finalize(stats, B, HW, G, gamma, beta, eps):
