@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--graphs", type=int, default=1,
                     help="graph executables replayed round-robin (measured: 1, 2 and 3 give the same step time, the "
                          "host-side launch of a replay already overlaps the previous one)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the graph executables are replayed on, round-robin: with 2, consecutive steps overlap "
+                         "(the MFMA-bound VAE encoder of step k+1 fills the CUs the latency-bound UNet of step k leaves idle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lora", action="store_true", help="enable one r=8 LoRA adapter (north_star variant)")
@@ -213,6 +216,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
     if rank == 0 and not args.no_kernel_profile:
         prof, event_overhead_us = kernel_profile(model, call)
 
+    fork = join = (lambda: None)
     if args.no_graph:
         def step():
             return model(*call)
@@ -223,31 +227,72 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
             model(*call)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        nexec = max(1, args.graphs, args.streams)
+        streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))] if args.streams > 1 else [None]
         graphs, outs = [], []
-        for _ in range(max(1, args.graphs)):
+        for i in range(nexec):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                outs.append(model(*call))
+            st = streams[i % len(streams)]
+            if st is not None:
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    model(*call)          # sizes this stream's split-K workspace outside the capture
+                st.synchronize()
+                with torch.cuda.graph(g, stream=st):
+                    outs.append(model(*call))
+            else:
+                with torch.cuda.graph(g):
+                    outs.append(model(*call))
             graphs.append(g)
         turn = [0]
 
         def step():
             i = turn[0] % len(graphs)
             turn[0] += 1
-            graphs[i].replay()
+            st = streams[i % len(streams)]
+            if st is None:
+                graphs[i].replay()
+            else:
+                with torch.cuda.stream(st):
+                    graphs[i].replay()
             return outs[i]
+
+        def fork():      # the side streams start after everything queued on the timing stream
+            for st in streams:
+                if st is not None:
+                    st.wait_stream(torch.cuda.current_stream())
+
+        def join():      # ... and the timing stream's closing event waits for all of them
+            for st in streams:
+                if st is not None:
+                    torch.cuda.current_stream().wait_stream(st)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    serial_ms = None
+    if not args.no_graph and args.streams > 1:
+        # reference point, outside the timed region: the same K steps strictly one after the other (one executable,
+        # one stream) -- the latency of a step; the timed region below overlaps consecutive steps on the streams
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st = streams[0]
+        with torch.cuda.stream(st):
+            a.record()
+            for _ in range(args.steps):
+                graphs[0].replay()
+            b.record()
+        torch.cuda.synchronize()
+        serial_ms = a.elapsed_time(b) / args.steps
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
+    fork()
     for _ in range(args.steps):
         step()
+    join()
     ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -274,8 +319,11 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
                        ("configs[2]: full MADM inference forward, RGB->Depth config (VAE enc -> UNet -> VAE dec -> "
                         f"GN projections -> DAFormer head @512x512, K=11), 1x3x{args.size}x{args.size} per GPU"),
                        "global_batch": args.batch * world, "parallelism": f"replicas x{world} (no collectives)",
-                       "launch": "eager" if args.no_graph else "hipGraph replay"},
+                       "launch": "eager" if args.no_graph else ("hipGraph replay" if args.streams <= 1 else
+                                                                f"hipGraph replay, {args.streams} streams (steps overlap)")},
             "device_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 4),
+            "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
+            "serial_images_per_s_per_gpu": None if serial_ms is None else round(args.batch / serial_ms * 1e3, 3),
             "whole_path_roofline_frac": round(value / world * alg / (peak * 1e12), 4),
         }
         if prof:
