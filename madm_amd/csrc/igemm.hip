@@ -32,9 +32,10 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc
     const int img0 = m0 / OHW;
     const bool one_image = (mlast / OHW) == img0;   // block-uniform
     const int nb = n0 + wn * (BN / 2) + fg * 4;
-    f32x4 cs[NI], cq[NI];
+    f32x4 cs[NI], cq[NI], add[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (p.splitk == 1) epilogue_consts<NI>(p, nb, one_image ? img0 : -1, add);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + frow;
@@ -48,7 +49,7 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc
                         make_float4(v[0], v[1], v[2], v[3]);
             }
         } else {
-            epilogue_row<T, NI>(p, m, nb, acc[i]);
+            epilogue_row<T, NI>(p, m, nb, add, !one_image, acc[i]);
             if (want_stats) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
@@ -63,12 +64,9 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    cs[j][r] += __shfl_xor(cs[j][r], o);
-                    cq[j][r] += __shfl_xor(cq[j][r], o);
-                }
+            for (int r = 0; r < 4; ++r) {
+                cs[j][r] = row16_sum(cs[j][r]);
+                cq[j][r] = row16_sum(cq[j][r]);
             }
             if (frow == 0) {
                 float* dst = red + ((wm * BN) + wn * (BN / 2) + j * 16 + fg * 4) * 2;

@@ -19,10 +19,10 @@ struct IgemmP {
 
 // GroupNorm finalize inside the consumer: gstat[g] = {mean_g, rstd_g} of image b from the per-channel sums.
 // All 256 threads: 8 lanes per group, every lane's loads in flight together, xor-shuffle reduction (f64 like
-// gn_apply_kernel / gn_finalize_kernel, so the three agree bit for bit).  The caller synchronises afterwards.
+// gn_apply_kernel / gn_finalize_kernel up to the final f32 rsqrt).  The caller synchronises afterwards.
 __device__ __forceinline__ void gn_fold_groups(const IgemmP& p, int b, float2* gstat) {
     const int G = p.gn_G, cpg = p.Ctot / G, C2 = p.Ctot - p.C1;
-    const double cnt = (double)(p.IH * p.IW) * (double)cpg;
+    const double inv_cnt = 1.0 / ((double)(p.IH * p.IW) * (double)cpg);
     for (int g0 = 0; g0 < G; g0 += 32) {
         const int g = g0 + ((int)threadIdx.x >> 3), l = threadIdx.x & 7;
         double s = 0.0, q = 0.0;
@@ -56,10 +56,12 @@ __device__ __forceinline__ void gn_fold_groups(const IgemmP& p, int b, float2* g
             q += __shfl_xor(q, o);
         }
         if (g < G && l == 0) {
-            const double mean = s / cnt;
-            double var = q / cnt - mean * mean;
+            // sums and the mean / variance algebra in f64 (cancellation), the reciprocal square root in f32: an f64
+            // divide + sqrt is ~100 instructions on this VALU and sat on every block's critical path
+            const double mean = s * inv_cnt;
+            double var = q * inv_cnt - mean * mean;
             if (var < 0.0) var = 0.0;
-            gstat[g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)p.gn_eps)));
+            gstat[g] = make_float2((float)mean, __builtin_amdgcn_rsqf((float)var + p.gn_eps));
         }
     }
 }
@@ -100,16 +102,66 @@ __device__ __forceinline__ f32x4 epilogue_store(const IgemmP& p, int m, int n, f
     }
 }
 
+// Per-lane constants of a tile epilogue: add[j] = bias[n_j .. n_j+3] (+ the time row of image ``img`` when the whole
+// tile lies in one image, img >= 0).  Loaded ONCE per lane before the row loop: inside it the compiler must assume the
+// output stores alias them and re-issued the loads for every row -- a full L2 round trip each, 9 000 of the 16 000
+// clocks of a 128 x 128 tile's epilogue (in-kernel stamps, tools/exp/stamps_block.py).
+template <int NI>
+__device__ __forceinline__ void epilogue_consts(const IgemmP& p, int nb, int img, f32x4 (&add)[NI]) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        add[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nb + 16 * j >= p.N) continue;
+        if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 16 * j);
+            add[j] = f32x4{b.x, b.y, b.z, b.w};
+        }
+        if (p.rowvec && img >= 0) {
+            const float4 t = *reinterpret_cast<const float4*>(p.rowvec + (size_t)img * p.ldrv + nb + 16 * j);
+            add[j][0] += t.x; add[j][1] += t.y; add[j][2] += t.z; add[j][3] += t.w;
+        }
+    }
+}
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4), result in every lane: four rotate-and-add steps on
+// the VALU instead of four ds_bpermute round trips
+__device__ __forceinline__ float row16_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));
+    return x;
+}
+
 // One output pixel row of a wave tile: NI chunks of 4 channels at n = nb + 16 * j.  All residual loads are issued
 // first and the NI stores leave back to back, so the (up to) four 32-byte pieces of one 128-byte output line reach
 // the L2 together (with a load -> store chain per chunk the L2 evicted half-written lines: 2x HBM write traffic
-// measured on the VAE ResNet convs).  v[j] returns the stored values (fused statistics).
+// measured on the VAE ResNet convs).  ``add`` = epilogue_consts; ``img_rows``: the time row was NOT folded into add
+// (tile straddles images) and is fetched per row.  v[j] returns the stored values (fused statistics).
 template <typename T, int NI>
-__device__ __forceinline__ void epilogue_row(const IgemmP& p, int m, int nb, f32x4 (&v)[NI]) {
+__device__ __forceinline__ void epilogue_row(const IgemmP& p, int m, int nb, const f32x4 (&add)[NI], bool img_rows,
+                                             f32x4 (&v)[NI]) {
+    const float* rv = (p.rowvec && img_rows) ? p.rowvec + (size_t)(m / (p.OH * p.OW)) * p.ldrv + nb : nullptr;
     if (p.epilogue == MADM_EPI_GEGLU) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-            if (nb + 16 * j < p.N) v[j] = epilogue_store<T>(p, m, nb + 16 * j, v[j]);
+        for (int j = 0; j < NI; ++j) {
+            const int n = nb + 16 * j;
+            if (n >= p.N) continue;
+            f32x4 t = v[j] + add[j];
+            if (rv) {
+                const float4 q = *reinterpret_cast<const float4*>(rv + 16 * j);
+                t[0] += q.x; t[1] += q.y; t[2] += q.z; t[3] += q.w;
+            }
+            float o0 = t[0] * gelu_erf_f(t[1]);
+            float o1 = t[2] * gelu_erf_f(t[3]);
+            const int col = n >> 1;
+            if (p.residual) {
+                const T* r = reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + col;
+                o0 += TT<T>::ld(r); o1 += TT<T>::ld(r + 1);
+            }
+            store2<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + col, o0, o1);
+            v[j] = f32x4{o0, o1, 0.f, 0.f};
+        }
         return;
     }
     f32x4 r[NI];
@@ -119,14 +171,10 @@ __device__ __forceinline__ void epilogue_row(const IgemmP& p, int m, int nb, f32
         for (int j = 0; j < NI; ++j)
             r[j] = (nb + 16 * j < p.N) ? load4<T>(rp + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float* rv = p.rowvec ? p.rowvec + (size_t)(m / (p.OH * p.OW)) * p.ldrv + nb : nullptr;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         if (nb + 16 * j >= p.N) continue;
-        if (p.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 16 * j);
-            v[j][0] += b.x; v[j][1] += b.y; v[j][2] += b.z; v[j][3] += b.w;
-        }
+        v[j] += add[j];
         if (rv) {
             const float4 t = *reinterpret_cast<const float4*>(rv + 16 * j);
             v[j][0] += t.x; v[j][1] += t.y; v[j][2] += t.z; v[j][3] += t.w;
