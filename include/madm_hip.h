@@ -131,11 +131,11 @@ int madm_conv2d_can_fuse_groupnorm(const madm_conv2d_args* a);
 /* which kernel instance madm_conv2d_fwd will launch for these arguments: 1 = igemm 128x128,
  * 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 x128 channels, 5 = halo conv3x3 x64 channels,
  * 6 = igemm 64x64 with the 8-deep prefetch, 7 / 8 = LDS-DMA igemm 64x64 / 128x64,
- * 9 / 10 = halo conv3x3 x128 / x64 with LDS-DMA weights
+ * 9 / 10 = halo conv3x3 x128 / x64 with LDS-DMA weights, 11 = LDS-DMA igemm 64x64 with the short ring
  * (used by bench.py to attribute time). */
 int madm_conv2d_pick_tile(const madm_conv2d_args* a);
 /* tuning/debug aid: force the workgroup tile (0 = tuned table then heuristic, -1 = heuristic only,
- * 1..10 = the tile codes of madm_conv2d_pick_tile). */
+ * 1..11 = the tile codes of madm_conv2d_pick_tile). */
 void madm_debug_set_conv_tile(int tile);
 
 /* ---------------------------------------------------------------------------------

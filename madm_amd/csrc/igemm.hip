@@ -253,7 +253,7 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() { GLDS_ASM("s_wa
 #endif
 
 template <typename T, int BM, int BN, int NS>
-__global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const IgemmP p) {
+__global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_kernel(const IgemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS address-space casts and gfx asm: device pass only (the host needs the stub)
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;
@@ -268,6 +268,12 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const IgemmP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+#ifdef GLDS_STAMPS
+#define GLDS_BSTAMP(k_) if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) g_glds_stamps[2000 + (k_)] = __builtin_readcyclecounter();
+#else
+#define GLDS_BSTAMP(k_)
+#endif
+    GLDS_BSTAMP(0);
     int bid = blockIdx.x;   // XCD-aware order, see igemm_kernel
     {
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
@@ -353,9 +359,11 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const IgemmP p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    GLDS_BSTAMP(1);
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (u < nt) GLDS_LOAD_TILE(kt0 + u, u);
+    GLDS_BSTAMP(2);
 
     const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
     unsigned aA[2], aB[2];   // LDS byte addresses of this lane's fragment chunk in slot 0 (rows + i * 16 via offset:)
@@ -427,8 +435,10 @@ __global__ __launch_bounds__(256, 2) void igemm_glds_kernel(const IgemmP p) {
         if (t + u < nt) GLDS_STEP(t + u, u, (u + NS - 1) % NS);
 #undef GLDS_STEP
 #undef GLDS_LOAD_TILE
+    GLDS_BSTAMP(3);
     __syncthreads();   // every wave is done with the last tile: the LDS becomes the statistics scratch
     igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(gsmem));
+    GLDS_BSTAMP(4);
 #endif
 }
 
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
 }
 
 int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
-inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8); }
+inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8) || t == 11; }
 inline bool is_halo_tile(int t) { return t == 4 || t == 5 || t == 9 || t == 10; }
 
 // Launch configurations measured on MI355X by tools/tune_insitu.py for the layer shapes of the SD-v1-4
@@ -528,7 +538,8 @@ bool halo_eligible(const madm_conv2d_args* a) {
 
 // tile codes: 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 BN=128, 5 = halo BN=64,
 // 6 = igemm 64x64 with an 8-deep register prefetch (latency-bound small-M GEMMs streaming cold weights),
-// 7 / 8 = LDS-DMA igemm 64x64 (4-slot ring) / 128x64 (3-slot ring), 9 / 10 = halo BN=128 / BN=64 with LDS-DMA weights
+// 7 / 8 = LDS-DMA igemm 64x64 (4-slot ring) / 128x64 (3-slot ring), 9 / 10 = halo BN=128 / BN=64 with LDS-DMA weights,
+// 11 = LDS-DMA igemm 64x64 with a 3-slot ring (48 KB: three blocks per CU, for grids of 513 .. 768 tiles)
 int pick_tile(const madm_conv2d_args* a) {
     const int M = a->B * a->OH * a->OW, K = a->KH * a->KW * (a->C1 + a->C2);
     const bool halo_ok = halo_eligible(a);
@@ -643,6 +654,7 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
         else if (t == 6) igemm_kernel<T, 64, 64, 8><<<grid, 256, 0, s>>>(p);
         else if (t == 7) { if (int e = launch_glds<T, 64, 64, 4>(p, grid, s)) return e; }
         else if (t == 8) { if (int e = launch_glds<T, 128, 64, 3>(p, grid, s)) return e; }
+        else if (t == 11) { if (int e = launch_glds<T, 64, 64, 3>(p, grid, s)) return e; }
         else igemm_kernel<T, 64, 64, 4><<<grid, 256, 0, s>>>(p);
         rc = madm_check_launch("igemm_kernel");
     }

@@ -62,6 +62,8 @@ CONV_CASES = [
     ("glds128_asym_s2", 2, [64], 16, 16, 128, 3, 2, "asym", False, 8, 1),
     ("glds128_1x1_longk_splitk", 2, [640], 8, 8, 640, 1, 1, "none", False, 8, 2),
     ("glds128_tiny_cout", 2, [64], 8, 8, 4, 3, 1, "same", False, 8, 1),
+    ("glds64s_1x1", 2, [320], 8, 8, 320, 1, 1, "none", False, 11, 1),
+    ("glds64s_ragged_3x3_splitk", 2, [128], 5, 7, 192, 3, 1, "same", False, 11, 2),
     # 9 / 10 = halo conv with LDS-DMA weights (three-slot ring, single halo buffer)
     ("halodma128", 2, [128], 16, 32, 256, 3, 1, "same", False, 9, 1),
     ("halodma64", 2, [64], 16, 16, 320, 3, 1, "same", False, 10, 1),

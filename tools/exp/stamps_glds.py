@@ -20,13 +20,15 @@ for i in range(9):
     ops.conv2d(x, ws[i % 8], B, hw, hw, N=cout, KH=k, KW=k, pad_t=k // 2, pad_l=k // 2, splitk=sk)
 torch.cuda.synchronize()
 n = (k * k * cin // 64) // sk
-buf = (ctypes.c_ulonglong * (4 * n))()
+buf = (ctypes.c_ulonglong * 2048)()
 fn = getattr(ctypes.CDLL(os.environ["MADM_HIP_LIB"]), "madm_debug_read_glds_stamps")
 fn.restype = ctypes.c_int
-assert fn(buf, 4 * n) == 0
+assert fn(buf, 2048) == 0
 st = [[buf[4 * s + j] for j in range(4)] for s in range(n)]
 print(f"M{B * hw * hw} N{cout} K{k * k * cin} tile {tile} sk{sk}: {n} steps/block, total {st[-1][3] - st[0][0]} clocks")
 print("step:  wait-DMA  barrier  issue+mfma | total   gap")
 for s in range(n):
     a, b, c, d = st[s]
     print(f"{s:4d}: {b - a:8d} {c - b:8d} {d - c:8d} | {d - a:6d} {(st[s + 1][0] - d) if s + 1 < n else 0:6d}")
+b = [buf[2000 + i] for i in range(5)]
+print(f"block 0: setup {b[1] - b[0]}  prologue DMA issue {b[2] - b[1]}  loop {b[3] - b[2]}  epilogue (issue only) {b[4] - b[3]}  total {b[4] - b[0]}")

@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 TILE_OF = {"igemm_128x128": 1, "igemm_128x64": 2, "igemm_64x64": 3, "conv3x3_halo_x128": 4, "conv3x3_halo_x64": 5,
            "igemm_64x64d": 6, "igemm_glds_64x64": 7, "igemm_glds_128x64": 8,
-           "conv3x3_halo_dma_x128": 9, "conv3x3_halo_dma_x64": 10}
+           "conv3x3_halo_dma_x128": 9, "conv3x3_halo_dma_x64": 10, "igemm_glds_64x64s": 11}
 
 
 def main():
@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--workload", default="extract", choices=["extract", "eval"])
-    ap.add_argument("--tiles", type=int, nargs="*", default=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+    ap.add_argument("--tiles", type=int, nargs="*", default=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
     ap.add_argument("--splitk", type=int, nargs="*", default=[1, 2, 3, 4, 6, 8, 12, 16, 24])
     args = ap.parse_args()
     from madm_amd.ldm_rocm import LdmRocm
