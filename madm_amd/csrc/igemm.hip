@@ -459,10 +459,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
     const int m = mbase + ty;
     const bool valid = m < p.M && n < p.N;
     if (valid) {
+        // everything the epilogue adds is requested BEFORE the slab round trips (it used to follow them: one more
+        // dependent L2 latency in a kernel that is nothing but latencies)
+        const bool plain = p.epilogue != MADM_EPI_GEGLU;
+        f32x4 add = f32x4{0.f, 0.f, 0.f, 0.f}, res = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (plain) {
+            if (p.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                add = f32x4{b.x, b.y, b.z, b.w};
+            }
+            if (p.rowvec) {
+                const float4 r = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / OHW) * p.ldrv + n);
+                add[0] += r.x; add[1] += r.y; add[2] += r.z; add[3] += r.w;
+            }
+            if (p.residual) res = load4<T>(reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + n);
+        }
         const float* src = p.ws + (size_t)m * p.N + n;
         const size_t slab = (size_t)p.M * p.N;
-        // slabs are summed in slab order (bit-reproducible), eight loads in flight per round: the slabs were written
-        // by other XCDs, every round is a full L2-miss latency and the kernel is nothing but those round trips
+        // slabs are summed in slab order (bit-reproducible), eight loads in flight per round
         for (int zz = 0; zz < p.splitk; zz += 8) {
             float4 t[8];
 #pragma unroll
@@ -473,7 +487,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
             for (int u = 0; u < 8; ++u)
                 if (zz + u < p.splitk) { v[0] += t[u].x; v[1] += t[u].y; v[2] += t[u].z; v[3] += t[u].w; }
         }
-        v = epilogue_store<T>(p, m, n, v);
+        if (plain) {
+            v += add;
+            if (p.residual) v += res;
+            if (p.epilogue == MADM_EPI_RELU) {
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            }
+            if (p.out_f32) store4<float>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n, v);
+            else store4<T>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
+        } else {
+            v = epilogue_store<T>(p, m, n, v);
+        }
         if (want_stats && !one_image) stats_add_elementwise(p, m, n, v);
     } else {
         v = f32x4{0.f, 0.f, 0.f, 0.f};
