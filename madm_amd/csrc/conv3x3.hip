@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256, (NWS == 2 || BN == 64) ? 2 : 1) void conv3x3_h
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.bytesw, 0x00020000);
 
     const int nchunks = p.Ctot / BKE;
-    const int ck0 = (int)(((long long)nchunks * z) / p.splitk);
-    const int ck1 = (int)(((long long)nchunks * (z + 1)) / p.splitk);
+    const int ck0 = (nchunks * z) / p.splitk;
+    const int ck1 = (nchunks * (z + 1)) / p.splitk;
     const int S = (ck1 - ck0) * 9;
 
     static_assert(NWS >= 2 && NWS % 2 == 0, "the weight ring must have an even number of stages");

@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.bytesw, 0x00020000);
 
     const int nchunks = p.Ctot / BKE;
-    const int ck0 = (int)(((long long)nchunks * z) / p.splitk);
-    const int ck1 = (int)(((long long)nchunks * (z + 1)) / p.splitk);
+    const int ck0 = (nchunks * z) / p.splitk;
+    const int ck1 = (nchunks * (z + 1)) / p.splitk;
     const int S = (ck1 - ck0) * 9;
 
     u32x4 hr[HI];
@@ -162,11 +162,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p
 
     if (S > 0) {
         D3_LOAD_HALO(ck0);
-        if (FUSE) gn_fold_groups(p, b, gstat);   // plain LDS stores: no DMA is in flight yet
+        D3_DMA_W();              // the first two weight tiles fly while the group statistics are folded and the
+        if (S > 1) D3_DMA_W();   // first halo chunk is normalised (the fold's plain LDS stores make the compiler drain
+        if (FUSE) gn_fold_groups(p, b, gstat);   // them: everything requested so far lands together)
         __syncthreads();
         D3_STORE_HALO(ck0);
-        D3_DMA_W();
-        if (S > 1) D3_DMA_W();
     }
 
     // fragment addressing: A chunk (kk, i) of tap (r, sx) = halo pixel h = (wm*4 + r + i) * HWD + frow + sx

@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
                                                                          p.in2 ? p.bytes2 : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.bytesw, 0x00020000);
 
-    const int kt0 = (int)(((long long)p.nk * z) / p.splitk);
-    const int kt1 = (int)(((long long)p.nk * (z + 1)) / p.splitk);
+    const int kt0 = (p.nk * z) / p.splitk;
+    const int kt1 = (p.nk * (z + 1)) / p.splitk;
     // tap state of the NEXT tile to load
     int c0, tr, ts;
     {
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_k
                                                                          p.in2 ? p.bytes2 : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.bytesw, 0x00020000);
 
-    const int kt0 = (int)(((long long)p.nk * z) / p.splitk);
-    const int kt1 = (int)(((long long)p.nk * (z + 1)) / p.splitk);
+    const int kt0 = (p.nk * z) / p.splitk;
+    const int kt1 = (p.nk * (z + 1)) / p.splitk;
     const int nt = kt1 - kt0;
     int c0, tr, ts;   // tap state of the NEXT tile to load
     {
@@ -638,6 +638,7 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     p.nk = p.K / bke;
     p.splitk = a->splitk > p.nk ? p.nk : a->splitk;
     if (p.splitk < 1) p.splitk = 1;
+    MADM_REQUIRE((long long)p.nk * (p.splitk + 1) < 0x7fffffffLL, "conv2d: K too large for the 32-bit slice arithmetic");
     return MADM_OK;
 }
 
