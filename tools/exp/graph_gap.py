@@ -4,7 +4,7 @@ run under rocprofv3 --kernel-trace and look at the first kernels of the last rep
 import os
 import sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from madm_amd import ops
 from madm_amd.ldm_rocm import LdmRocm
