@@ -12,6 +12,12 @@
 #include "igemm_common.hpp"
 
 namespace {
+#ifdef GLDS_STAMPS   // tools/exp/stamps_reg.py: block-level timeline of one block of the register-staged kernel
+__device__ unsigned long long g_reg_stamps[64];
+#define REG_BSTAMP(k_) if (blockIdx.x == 7 && blockIdx.z == 0 && threadIdx.x == 0) g_reg_stamps[(k_)] = __builtin_readcyclecounter();
+#else
+#define REG_BSTAMP(k_)
+#endif
 
 // ---- tile epilogue shared by the register-staged and the LDS-DMA kernels ----------------------------------------
 // lane holds pixel m (lane & 15), channels n .. n+3 (4 * (lane >> 4)) of each 16x16 sub-tile.
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
     __shared__ __attribute__((aligned(16))) uint4 smem[2 * (BM + BN) * 8];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    REG_BSTAMP(0);
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware order: blocks b and b+8 share an XCD (round-robin dispatch), so give every XCD a contiguous
     // range of tiles -- neighbouring output rows re-read the same input lines / weight panels from ITS L2.
@@ -192,6 +199,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
     // Pipeline: LDS buffer ((t - kt0) & 1) holds tile t; register stage (t + j) % NST holds tile t + j for
     // j = 1 .. NST-1; the loads of tile t + NST are issued before the MFMAs of tile t into the stage that held
     // tile t, and get NST MFMA phases to land (small grids have no co-resident block to hide the latency).
+    REG_BSTAMP(1);
 #pragma unroll
     for (int u = 0; u < NST; ++u)
         if (kt0 + u < kt1) IGEMM_LOAD_TILE(kt0 + u, ra[u], rb[u]);
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
                 _Pragma("unroll") for (int j = 0; j < NI; ++j) mma16<T>(wf[j], af[i], acc[i][j]);   \
         }                                                                                           \
     }
+    REG_BSTAMP(2);
     for (int kt = kt0; kt < kt1; kt += NST) {
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
@@ -233,7 +242,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
 #undef IGEMM_LOAD_TILE
 #undef IGEMM_STORE_TILE
 
+    REG_BSTAMP(3);
     igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(smem));
+    REG_BSTAMP(4);
+#ifdef GLDS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    REG_BSTAMP(5);
+#endif
 }
 
 // ---- LDS-DMA variant ----------------------------------------------------------------------------------------------
@@ -697,6 +712,9 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
 extern "C" {
 
 #ifdef GLDS_STAMPS
+int madm_debug_read_reg_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_reg_stamps), sizeof(unsigned long long) * n);
+}
 int madm_debug_read_glds_stamps(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_glds_stamps), sizeof(unsigned long long) * n);
 }
