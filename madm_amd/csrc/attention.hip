@@ -223,8 +223,16 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                     mx = fmaxf(mx, v);
                 }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // row maximum over the four lane groups of a query: v_permlane16/32_swap (VALU) instead of two ds_bpermute round
+        // trips -- this exchange sits on the critical path of every KV tile (the exponentials wait for it)
+        {
+            const unsigned xi = __builtin_bit_cast(unsigned, mx);
+            const auto r16 = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, r16[0]), __builtin_bit_cast(float, r16[1]));
+            const unsigned yi = __builtin_bit_cast(unsigned, mx);
+            const auto r32 = __builtin_amdgcn_permlane32_swap(yi, yi, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, r32[0]), __builtin_bit_cast(float, r32[1]));
+        }
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
