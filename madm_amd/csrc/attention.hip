@@ -12,6 +12,12 @@
 #include "common.hpp"
 
 namespace {
+#ifdef ATTN_STAMPS   // tools/exp/stamps_attn.py: shader-clock stamps per KV tile (block 0 / wave 0)
+__device__ unsigned long long g_attn_stamps[1024];
+#define A_STAMP(t_, k_) if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && (t_) < 128) g_attn_stamps[(t_) * 8 + (k_)] = __builtin_readcyclecounter();
+#else
+#define A_STAMP(t_, k_)
+#endif
 
 struct AttnP {
     const char* q; const char* k; const char* v; char* o;
@@ -175,6 +181,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
     }
 
     for (int t = 0; t < ntiles; ++t) {
+        A_STAMP(t, 0);
         const int k0 = t * C::BKV;
         const int cur = C::PIPE ? (t & 1) : 0;
         const bool more = t + 1 < ntiles;
@@ -200,6 +207,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                 mma16<T>(kf, qf, s[st]);
             }
         }
+        A_STAMP(t, 1);
         // ---- online softmax (base-2), one query per lane ----
         float mx = -INFINITY;
         if (k0 + C::BKV <= p.Lk) {   // full tile: no masking (wave-uniform)
@@ -249,6 +257,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
 #pragma unroll
         for (int d = 0; d < ND; ++d) o[d] *= alpha;
 
+        A_STAMP(t, 2);
         // ---- O^T += V^T P^T ----
         if constexpr (sizeof(T) == 2) {
             static_assert(sizeof(T) != 2 || NS % 2 == 0, "bf16 path pairs key sub-tiles");
@@ -292,11 +301,14 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                 }
             }
         }
+        A_STAMP(t, 3);
         // ---- hand the next tile over ----
         if constexpr (C::PIPE) {
             __builtin_amdgcn_sched_barrier(0);
             if (more) ATTN_STORE_KV(cur ^ 1);
+            A_STAMP(t, 4);
             __syncthreads();
+            A_STAMP(t, 5);
         } else {
             __syncthreads();   // everyone done with the single buffer
             if (more) ATTN_STAGE_DIRECT(k0 + C::BKV);
@@ -345,6 +357,12 @@ int launch_attn(const AttnP& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef ATTN_STAMPS
+extern "C" int madm_debug_read_attn_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 extern "C" int madm_attention_fwd(const madm_attention_args* a, void* stream) {
     MADM_REQUIRE(a && a->q && a->k && a->v && a->o, "attention: null pointer");
