@@ -294,6 +294,12 @@ class LdmRocm(nn.Module):
 
     @torch.no_grad()
     def forward(self, batched_inputs, input_modal, **kwargs):
+        # two stages with a narrow hand-over (the noisy latents), so that a serving loop can capture / schedule them
+        # separately (measured: free-running whole forwards on two streams beat the strict encoder || UNet pipeline)
+        return self._stage_unet(self._stage_encode(batched_inputs), batched_inputs, **kwargs)
+
+    def _stage_encode(self, batched_inputs):
+        """normalise -> vae_encoder -> timestep draw -> add_noise (ldm_diffusers.py:143-163); returns the hand-over."""
         images = batched_inputs['img']
         dtype = self.compute_dtype
         dev = images.device
@@ -305,8 +311,6 @@ class LdmRocm(nn.Module):
             minmax = torch.empty(2, device=dev)
             minmax.copy_(self._minmax_init)
         x = _img_tokens(images, dtype, mean, std, minmax)
-        text_prompt = batched_inputs['cond_inputs']
-        res_time_embedding = batched_inputs['cond_emb']
 
         # latents (vae_encoder) + timesteps + add_noise, the last two fused into one kernel
         moments, enc_taps = self.vae.encode_moments(x, tuple(self.encoder_block_indices))
@@ -322,6 +326,16 @@ class LdmRocm(nn.Module):
         latents, noisy = ops.latents_add_noise(moments.t, self.vae.config.scaling_factor, noise, sa, sn, timesteps,
                                                B, h * w, ops.k_tile(dtype), h, w)
         self.last_latents = latents
+        return {"B": B, "h": h, "w": w, "noisy": noisy, "latents": latents, "timesteps": timesteps, "enc_taps": enc_taps,
+                "minmax": minmax}
+
+    def _stage_unet(self, st, batched_inputs, **kwargs):
+        """diffusion_unet on the noisy latents + the feature hand-over (ldm_diffusers.py:165-217)."""
+        dtype = self.compute_dtype
+        B, h, w = st["B"], st["h"], st["w"]
+        noisy, latents, timesteps, enc_taps, minmax = st["noisy"], st["latents"], st["timesteps"], st["enc_taps"], st["minmax"]
+        text_prompt = batched_inputs['cond_inputs']
+        res_time_embedding = batched_inputs['cond_emb']
 
         if 'ema_forward' in kwargs.keys() and kwargs['ema_forward'] and hasattr(self, 'ema_unet'):
             forward_unet = self.ema_unet
