@@ -267,7 +267,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { GLDS_ASM("s_wait
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() { GLDS_ASM("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 #endif
 
-template <typename T, int BM, int BN, int NS>
+// LIN: 1x1 / stride 1 / no padding / no upsampling (every linear layer and 1x1 conv): output row m reads input row m, so
+// the gather needs no pixel arithmetic -- neither in the set-up (two integer divisions per staged row) nor per DMA
+// instruction (the address is row * ld + channel offset).
+template <typename T, int BM, int BN, int NS, bool LIN>
 __global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_kernel(const IgemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS address-space casts and gfx asm: device pass only (the host needs the stub)
     constexpr int EPC = TT<T>::EPC;
@@ -312,11 +315,15 @@ __global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_k
         if (row < BM) {
             const int m = m0 + row;
             if (m < p.M) {
-                const int b = m / OHW;
-                const int r = m - b * OHW;
-                const int oy = r / p.OW;
-                const int ox = r - oy * p.OW;
-                a_b[i] = b * p.IH; a_iy[i] = oy * p.stride - p.pad_t; a_ix[i] = ox * p.stride - p.pad_l;
+                if constexpr (LIN) {
+                    a_b[i] = m; a_iy[i] = 0;   // a_b = input row, a_iy >= 0 marks it valid
+                } else {
+                    const int b = m / OHW;
+                    const int r = m - b * OHW;
+                    const int oy = r / p.OW;
+                    const int ox = r - oy * p.OW;
+                    a_b[i] = b * p.IH; a_iy[i] = oy * p.stride - p.pad_t; a_ix[i] = ox * p.stride - p.pad_l;
+                }
             }
         } else {
             const int n = n0 + row - BM;
@@ -355,11 +362,16 @@ __global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_k
             const int q = wave * LPT + i;                                                                        \
             lds_char* dst = lds0 + ((slot) * TILE_U4 + q * 64) * 16;                                             \
             if (q * 8 < BM) {   /* wave-uniform */                                                               \
-                const int iy = a_iy[i] + tr, ix = a_ix[i] + ts;                                                  \
-                const bool ok = (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;                    \
-                const unsigned off = (unsigned)(((a_b[i] + (iy >> ush)) * p.IW + (ix >> ush)) * ld + cbase +     \
-                                                (int)swz[i]) * (unsigned)sizeof(T);                              \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, ok ? off : OOB, 0, 0, 0);                  \
+                if constexpr (LIN) {                                                                             \
+                    const unsigned off = (unsigned)(a_b[i] * ld + cbase + (int)swz[i]) * (unsigned)sizeof(T);    \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, a_iy[i] >= 0 ? off : OOB, 0, 0, 0);    \
+                } else {                                                                                         \
+                    const int iy = a_iy[i] + tr, ix = a_ix[i] + ts;                                              \
+                    const bool ok = (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;                \
+                    const unsigned off = (unsigned)(((a_b[i] + (iy >> ush)) * p.IW + (ix >> ush)) * ld + cbase + \
+                                                    (int)swz[i]) * (unsigned)sizeof(T);                          \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, ok ? off : OOB, 0, 0, 0);              \
+                }                                                                                                \
             } else {                                                                                             \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, dst, 16, wvoff[i], kofs, 0, 0);                    \
             }                                                                                                    \
@@ -657,10 +669,10 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     return MADM_OK;
 }
 
-template <typename T, int BM, int BN, int NS>
-int launch_glds(const IgemmP& p, dim3 grid, hipStream_t s) {
+template <typename T, int BM, int BN, int NS, bool LIN>
+int launch_glds_v(const IgemmP& p, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
-    auto kern = igemm_glds_kernel<T, BM, BN, NS>;
+    auto kern = igemm_glds_kernel<T, BM, BN, NS, LIN>;
     static bool attr_set = false;
     if (!attr_set) {
         if (lds > 64 * 1024) {
@@ -675,6 +687,13 @@ int launch_glds(const IgemmP& p, dim3 grid, hipStream_t s) {
     }
     kern<<<grid, 256, lds, s>>>(p);
     return MADM_OK;
+}
+
+template <typename T, int BM, int BN, int NS>
+int launch_glds(const IgemmP& p, dim3 grid, hipStream_t s) {
+    const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && !p.upsample &&
+                     p.OH == p.IH && p.OW == p.IW;
+    return lin ? launch_glds_v<T, BM, BN, NS, true>(p, grid, s) : launch_glds_v<T, BM, BN, NS, false>(p, grid, s);
 }
 
 template <typename T>
