@@ -90,7 +90,7 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc
     }
 }
 
-template <typename T, int BM, int BN, int NST>
+template <typename T, int BM, int BN, int NST, bool LIN>   // LIN: the linear fast path, see igemm_glds_kernel
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_kernel(const IgemmP p) {
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;            // elements per K tile (128 B per row)
@@ -124,11 +124,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + lrow + 32 * i;
         if (m < p.M) {
-            const int b = m / OHW;
-            const int r = m - b * OHW;
-            const int oy = r / p.OW;
-            const int ox = r - oy * p.OW;
-            a_b[i] = b * p.IH; a_iy[i] = oy * p.stride - p.pad_t; a_ix[i] = ox * p.stride - p.pad_l;
+            if constexpr (LIN) {
+                a_b[i] = m; a_iy[i] = 0; a_ix[i] = 0;   // a_b = input row, a_iy >= 0 marks it valid
+            } else {
+                const int b = m / OHW;
+                const int r = m - b * OHW;
+                const int oy = r / p.OW;
+                const int ox = r - oy * p.OW;
+                a_b[i] = b * p.IH; a_iy[i] = oy * p.stride - p.pad_t; a_ix[i] = ox * p.stride - p.pad_l;
+            }
         } else {
             a_b[i] = 0; a_iy[i] = -(1 << 24); a_ix[i] = 0;  // never in range
         }
@@ -168,11 +172,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
         const int ld = first ? p.ld1 : p.ld2;                                                    \
         const int cofs = (first ? c0 : c0 - p.C1) + chunk * EPC;                                 \
         _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                         \
-            const int iy = a_iy[i] + tr, ix = a_ix[i] + ts;                                      \
-            const bool ok = (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;        \
-            const unsigned off = (unsigned)(((a_b[i] + (iy >> ush)) * p.IW + (ix >> ush)) * ld + cofs) * \
-                                 (unsigned)sizeof(T);                                            \
-            RA_[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);            \
+            if constexpr (LIN) {                                                                 \
+                const unsigned off = (unsigned)(a_b[i] * ld + cofs) * (unsigned)sizeof(T);       \
+                RA_[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, a_iy[i] >= 0 ? off : OOB, 0, 0); \
+            } else {                                                                             \
+                const int iy = a_iy[i] + tr, ix = a_ix[i] + ts;                                  \
+                const bool ok = (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;    \
+                const unsigned off = (unsigned)(((a_b[i] + (iy >> ush)) * p.IW + (ix >> ush)) * ld + cofs) * \
+                                     (unsigned)sizeof(T);                                        \
+                RA_[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0);        \
+            }                                                                                    \
         }                                                                                        \
         const unsigned kofs = (unsigned)(kt) * (unsigned)(BKE * sizeof(T));                      \
         _Pragma("unroll") for (int i = 0; i < RB; ++i)                                           \
@@ -708,13 +717,17 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
         p.tilesN = (p.N + bn - 1) / bn;
         const int tilesM = (p.M + bm - 1) / bm;
         dim3 grid((unsigned)(tilesM * p.tilesN), 1, (unsigned)p.splitk);
-        if (t == 1) igemm_kernel<T, 128, 128, 2><<<grid, 256, 0, s>>>(p);
-        else if (t == 2) igemm_kernel<T, 128, 64, 3><<<grid, 256, 0, s>>>(p);
-        else if (t == 6) igemm_kernel<T, 64, 64, 8><<<grid, 256, 0, s>>>(p);
+        const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && !p.upsample &&
+                         p.OH == p.IH && p.OW == p.IW;
+        if (t == 1) igemm_kernel<T, 128, 128, 2, false><<<grid, 256, 0, s>>>(p);
+        else if (t == 2 && lin) igemm_kernel<T, 128, 64, 3, true><<<grid, 256, 0, s>>>(p);
+        else if (t == 2) igemm_kernel<T, 128, 64, 3, false><<<grid, 256, 0, s>>>(p);
+        else if (t == 6) igemm_kernel<T, 64, 64, 8, false><<<grid, 256, 0, s>>>(p);
         else if (t == 7) { if (int e = launch_glds<T, 64, 64, 4>(p, grid, s)) return e; }
         else if (t == 8) { if (int e = launch_glds<T, 128, 64, 3>(p, grid, s)) return e; }
         else if (t == 11) { if (int e = launch_glds<T, 64, 64, 3>(p, grid, s)) return e; }
-        else igemm_kernel<T, 64, 64, 4><<<grid, 256, 0, s>>>(p);
+        else if (lin) igemm_kernel<T, 64, 64, 4, true><<<grid, 256, 0, s>>>(p);
+        else igemm_kernel<T, 64, 64, 4, false><<<grid, 256, 0, s>>>(p);
         rc = madm_check_launch("igemm_kernel");
     }
     if (rc) return rc;
