@@ -169,60 +169,70 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p
         D3_STORE_HALO(ck0);
     }
 
-    // fragment addressing: A chunk (kk, i) of tap (r, sx) = halo pixel h = (wm*4 + r + i) * HWD + frow + sx
-    const unsigned wfrag = (unsigned)(((wn * (BN / 2) + frow) * 8) * 16);   // + j * 2048 + ((fg + 4kk) ^ (frow & 7)) * 16
-    int ck = ck0, tap = 0, cur = 0;
-    for (int s = 0; s < S; ++s) {
+    // fragment addressing, all of it hoisted out of the tap loop (the nine taps are unrolled: tap, ring slot and the halo
+    // row / column shift are compile-time, a fragment address is a precomputed register -- or that register ^ 64 for the
+    // second k-step -- plus an immediate): A chunk (kk, i) of tap (r, sx) = halo pixel (wm*4 + r + i) * HWD + frow + sx,
+    // 6 rows x 3 shifts = 18 addresses per lane; the per-tap index arithmetic was ~60 VALU instructions of every step.
+    unsigned ah[18];
+#pragma unroll
+    for (int ri = 0; ri < 6; ++ri)
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) {
+            const int h_ = (wm * 4 + ri) * HWD + frow + sx;
+            ah[ri * 3 + sx] = lds_base + (unsigned)(h_ * 8 + (fg ^ (h_ & 7))) * 16u;   // k-step 1: chunk fg + 4 = this ^ 64 bytes
+        }
+    const unsigned wf0 = wring + (unsigned)(((wn * (BN / 2) + frow) * 8 + (fg ^ (frow & 7))) * 16);   // + slot, + j * 2048; ^ 64
+    const unsigned wf1 = wf0 ^ 64u;
+    for (int ck = ck0; ck < ck1; ++ck) {
         const bool next_chunk = (ck + 1 < ck1);
-        // weight tile s has landed once at most the next tile's LW loads of this wave are outstanding (the halo loads
-        // of tap 0 are issued BEFORE that tile's DMA, so they are older and covered by the same wait)
-        if (s + 1 < S) c3_wait_vmcnt<LW>();
-        else c3_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();   // tile s (and at tap 0 the new halo) visible; ring slot (s + 2) % 3 is free
-        if (tap == 0 && next_chunk) D3_LOAD_HALO(ck + 1);
-        if (s + 2 < S) D3_DMA_W();
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const int r_ = tap / 3, sx_ = tap - 3 * r_;
-            const int hb_ = (wm * 4 + r_) * HWD + frow + sx_;
-            const unsigned wslot = wring + (unsigned)(cur * W_U4 * 16) + wfrag;
-            u32x4 af[2][MI], wf[2][NI];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int c_ = fg + 4 * kk;
+        for (int tap = 0; tap < 9; ++tap) {
+            constexpr int kW_BYTES = W_U4 * 16;
+            const int cur = tap % 3;   // 9 taps per chunk: the ring slot of a tap is the same in every chunk
+            // weight tile s has landed once at most the next tile's LW loads of this wave are outstanding (the halo loads
+            // of tap 0 are issued BEFORE that tile's DMA, so they are older and covered by the same wait)
+            if (tap < 8 || next_chunk) c3_wait_vmcnt<LW>();
+            else c3_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();   // this tap's tile (and at tap 0 the new halo) visible; ring slot (tap + 2) % 3 is free
+            if (tap == 0 && next_chunk) D3_LOAD_HALO(ck + 1);
+            if (tap < 7 || next_chunk) D3_DMA_W();
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int r_ = tap / 3, sx_ = tap % 3;
+                u32x4 af[2][MI], wf[2][NI];
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int h_ = hb_ + i * HWD;
-                    const unsigned a_ = lds_base + (unsigned)(h_ * 8 + (c_ ^ (h_ & 7))) * 16u;
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(af[kk][i]) : "v"(a_));
-                }
-                const unsigned w_ = wslot + (unsigned)((c_ ^ (frow & 7)) * 16);
+                for (int i = 0; i < MI; ++i)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(af[0][i]) : "v"(ah[(r_ + i) * 3 + sx_]));
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[kk][j]) : "v"(w_), "n"(j * 2048));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[0][j]) : "v"(wf0), "n"(cur * kW_BYTES + j * 2048));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(af[1][i]) : "v"(ah[(r_ + i) * 3 + sx_] ^ 64u));
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[1][j]) : "v"(wf1), "n"(cur * kW_BYTES + j * 2048));
+                c3_wait_lgkmcnt<MI + NI>();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        mma16<T>(__builtin_bit_cast(uint4, wf[0][j]), __builtin_bit_cast(uint4, af[0][i]), acc[i][j]);
+                c3_wait_lgkmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        mma16<T>(__builtin_bit_cast(uint4, wf[1][j]), __builtin_bit_cast(uint4, af[1][i]), acc[i][j]);
             }
-            c3_wait_lgkmcnt<MI + NI>();
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    mma16<T>(__builtin_bit_cast(uint4, wf[0][j]), __builtin_bit_cast(uint4, af[0][i]), acc[i][j]);
-            c3_wait_lgkmcnt<0>();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    mma16<T>(__builtin_bit_cast(uint4, wf[1][j]), __builtin_bit_cast(uint4, af[1][i]), acc[i][j]);
+            if (tap == 8 && next_chunk) {
+                __builtin_amdgcn_s_barrier();   // single halo buffer: every wave has read its last fragments of this chunk
+                D3_STORE_HALO(ck + 1);          // published by the barrier that opens the next tap
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (tap == 8 && next_chunk) {
-            __builtin_amdgcn_s_barrier();   // single halo buffer: every wave has read its last fragments of this chunk
-            D3_STORE_HALO(ck + 1);          // published by the barrier that opens the next tap
-        }
-        cur = (cur == 2) ? 0 : cur + 1;
-        if (++tap == 9) { tap = 0; ++ck; }
     }
 #undef D3_LOAD_HALO
 #undef D3_STORE_HALO
