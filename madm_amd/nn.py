@@ -124,8 +124,8 @@ class Conv2d(_Packed):
         dtype = x.t.dtype
         gn = None
         if norm is not None:
-            # folding the norm into the conv re-applies it once per 128-channel output tile: it pays only when the
-            # conv has a single output tile (measured on MI355X; wider layers run gn_apply once + the plain conv)
+            # folding the norm into the conv re-applies it once per output-channel tile: measured on MI355X it pays up to
+            # 256 output channels (ops.FUSE_GN_MAX_N); wider layers run gn_apply once + the plain conv
             if self.out_channels <= ops.FUSE_GN_MAX_N and ops.can_fuse_groupnorm(
                     x.H, x.W, self.kernel_size, self.stride, self.padding, self.asym_pad, upsample):
                 srcs = [x] if x2 is None else [x, x2]

@@ -53,9 +53,10 @@ FORCE_SPLITK = None   # tools/tune_insitu.py: split-K factor forced on every sma
 FUSE_GN = True   # fold GroupNorm(+SiLU) into eligible 3x3 convs (debug switch)
 HALO_MIN_W = int(__import__("os").environ.get("MADM_HALO_MIN_W", "8"))   # mirrors halo_min_width() of igemm.hip
 import os as _os
-FUSE_GN_MAX_N = int(_os.environ.get("MADM_FUSE_GN_MAX_N", "1000000"))   # ... of any width: with the rcp-based SiLU the
-# transform redone per output tile costs less than a stand-alone GroupNorm pass + launch (same-box A/B: 128 -> 192.9,
-# 320 -> 194.1, 640 -> 195.2, unlimited -> 196.3 images/s); env override for A/B runs
+FUSE_GN_MAX_N = int(_os.environ.get("MADM_FUSE_GN_MAX_N", "256"))   # ... whose output has at most 256 channels: the
+# transform is redone once per output-channel tile, so on the wide UNet layers (320 .. 1280 channels, 5 .. 20 tiles of 64) a
+# stand-alone GroupNorm pass + the plain conv is less total work.  Same-box A/B with both variants tuned (images/s,
+# overlapped / serial): 128 -> 269 / 220, 256 -> 270 / 220, unlimited -> 262 / 221.  Env override for A/B runs.
 
 
 def can_fuse_groupnorm(IH, IW, KH, stride, pad, asym_pad, upsample):

@@ -33,9 +33,21 @@ def rows_of(path):
 
 
 def main():
-    extract = rows_of(sys.argv[1])
+    """apply_tuned.py <extract.txt>[,<extract2.txt>...] [<eval.txt>[,<eval2.txt>...]]
+    Several tuner outputs (e.g. tuned under different GroupNorm-fusion policies, so that both the plain and the fused
+    variant of a shape are covered) are merged; for a key present in several files the FIRST file wins."""
+    def merged(arg):
+        out, seen = [], set()
+        for path in arg.split(","):
+            for r in rows_of(path):
+                if r[:6] not in seen:
+                    seen.add(r[:6])
+                    out.append(r)
+        return sorted(out)
+
+    extract = merged(sys.argv[1])
     if len(sys.argv) > 2:
-        ev = rows_of(sys.argv[2])
+        ev = merged(sys.argv[2])
     else:
         ev, on = [], False
         for line in open(INC):
@@ -47,9 +59,11 @@ def main():
     keys = {r[:6] for r in extract}
     ev = [r for r in ev if r[:6] not in keys]
     with open(INC, "w") as f:
-        f.write("// {dtype (0 f32, 1 bf16), M, N, K, KH, variant (0 plain, 1 GroupNorm-fused, 2 upsample), tile (1=128x128, 2=128x64, 3=64x64 igemm; 4 = halo conv3x3 x128, "
-                "5 = halo x64; 6 = 64x64 igemm with the 8-deep prefetch), splitk}\n")
-        f.write("// measured by tools/tune_insitu.py on MI355X (whole eager forwards, cold weights), bf16, round 1\n")
+        f.write("// {dtype (0 f32, 1 bf16), M, N, K, KH, variant (0 plain, 1 GroupNorm-fused, 2 upsample), tile (1=128x128, "
+                "2=128x64, 3=64x64 igemm; 4 / 5 = halo conv3x3 x128 / x64; 6 = 64x64 igemm, 8-deep prefetch; 7 / 8 / 11 = "
+                "LDS-DMA igemm 64x64 / 128x64 / 64x64 short ring; 9 / 10 = LDS-DMA halo x128 / x64), splitk}\n")
+        f.write("// measured by tools/tune_insitu.py on MI355X (whole eager forwards, cold weights), bf16, round 1; plain and\n"
+                "// GroupNorm-fused variants come from runs under different fusion policies (MADM_FUSE_GN_MAX_N)\n")
         f.write("// -- feature extractor, bs=2, 512x512 (BASELINE configs[1])\n")
         for r in extract:
             f.write("{%d, %d, %d, %d, %d, %d, %d, %d},\n" % r)
