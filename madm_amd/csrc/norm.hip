@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     float* grstd = gmean + G;
     const int b = blockIdx.y;
     const int cpg = Ctot / G;
-    const double cnt = (double)HW * (double)cpg;
+    const double inv_cnt = 1.0 / ((double)HW * (double)cpg);
     const int C2 = Ctot - C1;
     const unsigned CPR = (unsigned)C / EPC;
     const unsigned total = (unsigned)HW * CPR;   // < 2^31 (checked by the launcher)
@@ -135,11 +135,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             q += __shfl_xor(q, o);
         }
         if (g < G && l == 0) {
-            const double mean = s / cnt;
-            double var = q / cnt - mean * mean;
+            // mean / variance algebra in f64, reciprocal square root in f32 -- exactly as the fused convs fold the same
+            // sums (igemm_common.hpp gn_fold_groups): an f64 divide + sqrt is ~100 instructions on the critical path
+            const double mean = s * inv_cnt;
+            double var = q * inv_cnt - mean * mean;
             if (var < 0.0) var = 0.0;
             gmean[g] = (float)mean;
-            grstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+            grstd[g] = __builtin_amdgcn_rsqf((float)var + eps);
         }
     }
     __syncthreads();
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(int HW, int Ctot, int 
     __shared__ float gmean[256], grstd[256];
     const int b = blockIdx.x;
     const int cpg = Ctot / G;
-    const double cnt = (double)HW * (double)cpg;
+    const double inv_cnt = 1.0 / ((double)HW * (double)cpg);
     const int C2 = Ctot - C1;
     for (int g0 = 0; g0 < G; g0 += 32) {
         const int g = g0 + (threadIdx.x >> 3), l = threadIdx.x & 7;
@@ -211,11 +213,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(int HW, int Ctot, int 
             q += __shfl_xor(q, o);
         }
         if (g < G && l == 0) {
-            const double mean = s / cnt;
-            double var = q / cnt - mean * mean;
+            // mean / variance algebra in f64, reciprocal square root in f32 -- exactly as the fused convs fold the same
+            // sums (igemm_common.hpp gn_fold_groups): an f64 divide + sqrt is ~100 instructions on the critical path
+            const double mean = s * inv_cnt;
+            double var = q * inv_cnt - mean * mean;
             if (var < 0.0) var = 0.0;
             gmean[g] = (float)mean;
-            grstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+            grstd[g] = __builtin_amdgcn_rsqf((float)var + eps);
         }
     }
     __syncthreads();
