@@ -297,6 +297,39 @@ int madm_tanh_gate(const float* a1, const float* x1, const float* a2, const floa
 int madm_argmax_nchw_f32(const float* x, int64_t* out, int B, int K, size_t HW, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * Backward of madm_conv2d_fwd.  The reference obtains these from torch autograd:
+ * losses.backward() / scaler.scale(losses).backward() in engine/train_loop.py:203-217 through every nn.Conv2d /
+ * nn.Linear / peft lora_A / lora_B executed under ldm_diffusers.py:283-616.
+ *
+ * Weight gradient:   dw[n][k] += sum_m dout[m][n] * A(m, k),  k = (kh, kw, c), A = the gather of madm_conv2d_fwd
+ * (same geometry fields, incl. the two-source concat and the nearest-2x upsample).  The inputs are the tensors the
+ * forward conv READ (a GroupNorm the forward fused must be materialised by the caller).  dw is f32 [N][K] dense and
+ * is ACCUMULATED into (gradient accumulation; zero it for a plain gradient); the pixel range is split over `splitm`
+ * grid slices (0 = choose) that add their partial tiles with float atomics, so the low-order bits depend on
+ * scheduling, like torch's own non-deterministic wgrad algorithms.
+ * bias gradient = column sums of dout: madm_groupnorm_stats(dout) gives them per image.
+ *
+ * Data gradient of a stride-1 layer (3x3 / pad 1, 1x1, linear): din = madm_conv2d_fwd(dout, wt) with
+ * pad' = KH - 1 - pad and wt[c][taps - 1 - t][n] = w[n][t][c], produced by madm_pack_dgrad_weights
+ * (w dense [N][taps][C], wt dense [C][taps][N]).
+ * ------------------------------------------------------------------------------- */
+typedef struct {
+    int dtype;            /* madm_dtype of in1 / in2 / dout */
+    const void* in1;      /* forward input [B, IH, IW, C1] (pixel stride ld1) */
+    const void* in2;      /* second source or NULL */
+    int C1, C2;           /* multiples of 8 (bf16) / 4 (f32) elements */
+    int ld1, ld2;         /* 0 = dense */
+    const void* dout;     /* [M][ldd], M = B*OH*OW: gradient of the forward output */
+    int ldd;              /* 0 = dense (N) */
+    float* dw;            /* f32 [N][KH*KW*(C1+C2)], accumulated into */
+    int B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
+    int N;                /* multiple of 4 */
+    int splitm;           /* pixel slices; 0 = choose for the MI355X grid */
+} madm_conv2d_wgrad_args;
+int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream);
+int madm_pack_dgrad_weights(int dtype, const void* w, void* wt, int N, int taps, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Training-step tail on ONE flat, 16-byte-aligned fp32 buffer per role (HBM-bound).
  * ------------------------------------------------------------------------------- */
 /* *out (f64, caller-zeroed) += sum x[i]^2 : the total norm of torch.nn.utils.clip_grad_norm_

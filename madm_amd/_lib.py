@@ -56,6 +56,21 @@ class Conv2dArgs(ctypes.Structure):
     ]
 
 
+class Conv2dWgradArgs(ctypes.Structure):
+    _fields_ = [
+        ("dtype", c_int),
+        ("in1", c_void_p), ("in2", c_void_p),
+        ("C1", c_int), ("C2", c_int),
+        ("ld1", c_int), ("ld2", c_int),
+        ("dout", c_void_p), ("ldd", c_int),
+        ("dw", c_void_p),
+        ("B", c_int), ("IH", c_int), ("IW", c_int), ("OH", c_int), ("OW", c_int),
+        ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad_t", c_int), ("pad_l", c_int), ("upsample", c_int),
+        ("N", c_int),
+        ("splitm", c_int),
+    ]
+
+
 class AttentionArgs(ctypes.Structure):
     _fields_ = [
         ("dtype", c_int),
@@ -121,6 +136,8 @@ SYMBOLS = [
     ("madm_class_mix", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
     ("madm_nchw_f32_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    ("madm_conv2d_wgrad", c_int, [ctypes.POINTER(Conv2dWgradArgs), c_void_p]),
+    ("madm_pack_dgrad_weights", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 ]
 
 

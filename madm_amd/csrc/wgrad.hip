@@ -1,0 +1,287 @@
+// Backward of madm_conv2d_fwd with respect to the weights, and the weight repack its data gradient needs.
+//   dw[n][k] += sum_m dout[m][n] * A(m, k)       k = (kh, kw, c), A = the gather of igemm.hip
+// Both operands of this GEMM are contiguous along the OUTPUT dims (n resp. c) and strided along the reduction dim (the
+// pixel m), i.e. both are needed transposed.  The tiles are staged into LDS as they lie in memory ([pixel][channel]
+// rows) and the MFMA fragments are read transposed: bf16 with ds_read_b64_tr_b16 (a 4-pixel x 16-channel block
+// transposed by the LDS: lane (fi, fg) receives pixels 4 fg .. 4 fg + 3 of channel fi), f32 with four ds_read_b32.
+// Lane group fg therefore holds pixels {4 fg + r, 16 + 4 fg + r} of a 32-pixel step in its eight k slots -- the same
+// permutation of the reduction index for both operands, so the sum is unchanged.
+// Block = 128 output channels x 128 weight columns, 4 waves 2 x 2, K loop over pixels in steps of 32 (bf16) / 16 (f32)
+// with a register-prefetch double buffer, grid.z slices the pixel range (the weight gradient of a 512 x 512 layer
+// reduces over 524 288 pixels into a 128 x 1152 tile: without slicing it would be nine blocks); partial tiles are
+// added into the f32 gradient with hardware float atomics -- which also gives the "+=" of gradient accumulation.
+// The data gradient of a stride-1 conv / linear layer is madm_conv2d_fwd itself on dout with the weights transposed
+// and the taps reversed: madm_pack_dgrad_weights produces that layout.
+// The reference gets both from torch autograd (loss.backward(), engine/train_loop.py:203-217).
+#include "common.hpp"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct WgradP {
+    const char* in1; const char* in2; const char* dout; float* dw;
+    int C1, C2, Ctot, ld1, ld2, ldd, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
+    int N, K, M, steps_per_slice, lin;
+    unsigned bytes1, bytes2, bytesd;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int PX = 4 * EPC;                  // pixels per K step: one MFMA k-extent (bf16 32, f32 16)
+    constexpr int CPR = 128 / EPC;               // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CPR;               // rows staged per pass of the block
+    constexpr int LI = PX / RPP;                 // passes (2)
+    constexpr int ROWB = 128 * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);   // padded: transposed reads conflict-free
+    constexpr int TILEB = PX * ROWB;
+    constexpr unsigned OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILEB];   // {dout, A} x 2 stages
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wc = wave >> 1;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 128, kc0 = blockIdx.y * 128;
+    const int cc = tid % CPR, r0 = tid / CPR;
+
+    const int step0 = blockIdx.z * p.steps_per_slice;
+    const int total_steps = (p.M + PX - 1) / PX;
+    const int nsteps = min(p.steps_per_slice, total_steps - step0);
+    if (nsteps <= 0) return;
+
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dout, 0, p.bytesd, 0x00020000);
+    // this thread's weight column: tap and channel are fixed, only the pixel moves
+    const int kc = kc0 + cc * EPC;
+    const bool kc_ok = kc < p.K;
+    const int tap = kc_ok ? kc / p.Ctot : 0;
+    const int c = kc - tap * p.Ctot;
+    const int tr = tap / p.KW, ts = tap - tr * p.KW;
+    const bool first = c < p.C1;
+    const __amdgpu_buffer_rsrc_t rsa =
+        first ? __builtin_amdgcn_make_buffer_rsrc((void*)p.in1, 0, p.bytes1, 0x00020000)
+              : __builtin_amdgcn_make_buffer_rsrc((void*)p.in2, 0, p.bytes2, 0x00020000);
+    const int lda = first ? p.ld1 : p.ld2;
+    const int ca = first ? c : c - p.C1;
+    const bool n_ok = n0 + cc * EPC < p.N;
+
+    // output pixel of staged row i: m = (step0 + s) * PX + r0 + RPP * i, kept as (image, y, x) and advanced by PX
+    int pm[LI], pb[LI], py[LI], px[LI];
+#pragma unroll
+    for (int i = 0; i < LI; ++i) {
+        pm[i] = step0 * PX + r0 + RPP * i;
+        const int q = pm[i] / p.OW;
+        px[i] = pm[i] - q * p.OW;
+        pb[i] = q / p.OH;
+        py[i] = q - pb[i] * p.OH;
+    }
+    const int IHe = p.upsample ? 2 * p.IH : p.IH, IWe = p.upsample ? 2 * p.IW : p.IW;
+
+    u32x4 rd[LI], ra[LI];
+    auto load_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < LI; ++i) {
+            const bool m_ok = pm[i] < p.M;
+            const unsigned offd = (unsigned)(pm[i] * p.ldd + n0 + cc * EPC) * (unsigned)sizeof(T);
+            rd[i] = __builtin_amdgcn_raw_buffer_load_b128(rsd, (m_ok && n_ok) ? offd : OOB, 0, 0);
+            unsigned offa = OOB;
+            if (m_ok && kc_ok) {
+                if (p.lin) {
+                    offa = (unsigned)(pm[i] * lda + ca) * (unsigned)sizeof(T);
+                } else {
+                    int iy = py[i] * p.stride - p.pad_t + tr, ix = px[i] * p.stride - p.pad_l + ts;
+                    if ((unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe) {
+                        if (p.upsample) { iy >>= 1; ix >>= 1; }
+                        offa = (unsigned)(((pb[i] * p.IH + iy) * p.IW + ix) * lda + ca) * (unsigned)sizeof(T);
+                    }
+                }
+            }
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, offa, 0, 0);
+            pm[i] += PX;
+            px[i] += PX;
+            while (px[i] >= p.OW) {
+                px[i] -= p.OW;
+                if (++py[i] == p.OH) { py[i] = 0; ++pb[i]; }
+            }
+        }
+    };
+    auto store_step = [&](int stage) {
+        char* d = smem + stage * 2 * TILEB;
+#pragma unroll
+        for (int i = 0; i < LI; ++i) {
+            const int off = (r0 + RPP * i) * ROWB + cc * 16;
+            *reinterpret_cast<u32x4*>(d + off) = rd[i];
+            *reinterpret_cast<u32x4*>(d + TILEB + off) = ra[i];
+        }
+    };
+
+    f32x4 acc[4][4];   // [jn: 16 output channels][ic: 16 weight columns]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_step();
+    store_step(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more = s + 1 < nsteps;
+        if (more) load_step();
+        const char* td = smem + (s & 1) * 2 * TILEB;
+        const char* ta = td + TILEB;
+        uint4 fd[4], fa[4];
+        if constexpr (sizeof(T) == 2) {
+            const int row = fg * 4 + (fi >> 2), colb = (fi & 3) * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* q = td + row * ROWB + (wn * 64 + j * 16) * 2 + colb;
+                const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)q);
+                const s16x4 x1 =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * ROWB));
+                const uint2 a0 = __builtin_bit_cast(uint2, x0), a1 = __builtin_bit_cast(uint2, x1);
+                fd[j] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const char* q = ta + row * ROWB + (wc * 64 + i * 16) * 2 + colb;
+                const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)q);
+                const s16x4 x1 =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * ROWB));
+                const uint2 a0 = __builtin_bit_cast(uint2, x0), a1 = __builtin_bit_cast(uint2, x1);
+                fa[i] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* q = td + (fg * 4) * ROWB + (wn * 64 + j * 16 + fi) * 4;
+                float4 v;
+                v.x = *reinterpret_cast<const float*>(q);
+                v.y = *reinterpret_cast<const float*>(q + ROWB);
+                v.z = *reinterpret_cast<const float*>(q + 2 * ROWB);
+                v.w = *reinterpret_cast<const float*>(q + 3 * ROWB);
+                fd[j] = __builtin_bit_cast(uint4, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const char* q = ta + (fg * 4) * ROWB + (wc * 64 + i * 16 + fi) * 4;
+                float4 v;
+                v.x = *reinterpret_cast<const float*>(q);
+                v.y = *reinterpret_cast<const float*>(q + ROWB);
+                v.z = *reinterpret_cast<const float*>(q + 2 * ROWB);
+                v.w = *reinterpret_cast<const float*>(q + 3 * ROWB);
+                fa[i] = __builtin_bit_cast(uint4, v);
+            }
+        }
+        // D[i][j] of mma16: i = row of the first operand (4 per lane), j = row of the second (lane & 15): the lane's
+        // column index runs along the contiguous dim of dw
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mma16<T>(fd[j], fa[i], acc[j][i]);
+        if (more) store_step((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // lane holds dw[n = nb + 4 fg + r][k = kb + fi]: one atomic instruction covers 4 rows x 64 contiguous bytes
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + fg * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = kc0 + wc * 64 + i * 16 + fi;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) unsafeAtomicAdd(p.dw + (size_t)(n + r) * p.K + k, acc[j][i][r]);
+        }
+    }
+}
+
+// wt[c][T - 1 - t][n] = w[n][t][c]: 32 x 32 tiles through LDS, coalesced on both sides
+template <typename T>
+__global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(const T* __restrict__ w, T* __restrict__ wt, int N,
+                                                                 int Tn, int C) {
+    __shared__ T tile[32][33];
+    const int t = blockIdx.z;
+    const int n0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, c = c0 + tx;
+        if (n < N && c < C) tile[ty + 8 * i][tx] = w[((size_t)n * Tn + t) * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, n = n0 + tx;
+        if (n < N && c < C) wt[((size_t)c * Tn + (Tn - 1 - t)) * N + n] = tile[tx][ty + 8 * i];
+    }
+}
+
+}  // namespace
+
+extern "C" int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream) {
+    MADM_REQUIRE(a && a->in1 && a->dout && a->dw, "conv2d_wgrad: null argument");
+    MADM_REQUIRE(a->dtype == MADM_F32 || a->dtype == MADM_BF16, "conv2d_wgrad: unknown dtype %d", a->dtype);
+    const int epc = a->dtype == MADM_BF16 ? 8 : 4;
+    const size_t esz = a->dtype == MADM_BF16 ? 2 : 4;
+    MADM_REQUIRE(a->C1 > 0 && a->C2 >= 0 && (a->C2 == 0 || a->in2), "conv2d_wgrad: bad channel split %d + %d", a->C1,
+                 a->C2);
+    MADM_REQUIRE(a->C1 % epc == 0 && a->C2 % epc == 0, "conv2d_wgrad: C1 / C2 must be multiples of %d elements", epc);
+    MADM_REQUIRE(a->N > 0 && a->N % 4 == 0, "conv2d_wgrad: N = %d must be a positive multiple of 4", a->N);
+    MADM_REQUIRE(a->B > 0 && a->IH > 0 && a->IW > 0 && a->OH > 0 && a->OW > 0 && a->KH > 0 && a->KW > 0 &&
+                     a->stride > 0,
+                 "conv2d_wgrad: bad geometry");
+    WgradP p;
+    p.in1 = (const char*)a->in1; p.in2 = (const char*)a->in2; p.dout = (const char*)a->dout; p.dw = a->dw;
+    p.C1 = a->C1; p.C2 = a->C2; p.Ctot = a->C1 + a->C2;
+    p.ld1 = a->ld1 ? a->ld1 : a->C1;
+    p.ld2 = a->ld2 ? a->ld2 : a->C2;
+    p.ldd = a->ldd ? a->ldd : a->N;
+    MADM_REQUIRE(p.ld1 % epc == 0 && p.ld2 % epc == 0 && p.ldd % 4 == 0, "conv2d_wgrad: row strides must keep 16-byte "
+                 "(dout: 8-byte) alignment");
+    p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.KH = a->KH; p.KW = a->KW;
+    p.stride = a->stride; p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.upsample = a->upsample ? 1 : 0;
+    p.N = a->N; p.K = a->KH * a->KW * p.Ctot;
+    const long long M = (long long)a->B * a->OH * a->OW;
+    const long long in_rows = (long long)a->B * a->IH * a->IW;
+    MADM_REQUIRE(M < (1ll << 30) && in_rows * p.ld1 * (long long)esz < (1ll << 31) &&
+                     in_rows * (long long)p.ld2 * (long long)esz < (1ll << 31) &&
+                     M * p.ldd * (long long)esz < (1ll << 31),
+                 "conv2d_wgrad: tensors must stay below 2 GiB");
+    p.M = (int)M;
+    p.bytes1 = (unsigned)(in_rows * p.ld1 * esz);
+    p.bytes2 = a->C2 ? (unsigned)(in_rows * p.ld2 * esz) : 0u;
+    p.bytesd = (unsigned)(M * p.ldd * esz);
+    p.lin = (a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad_t == 0 && a->pad_l == 0 && !a->upsample &&
+             a->OH == a->IH && a->OW == a->IW)
+                ? 1 : 0;
+    const int px = 4 * epc;
+    const int total_steps = (p.M + px - 1) / px;
+    const int tilesN = (p.N + 127) / 128, tilesK = (p.K + 127) / 128;
+    int splitm = a->splitm;
+    if (splitm <= 0) {   // ~4 blocks per CU, at least 8 steps per slice
+        splitm = (1024 + tilesN * tilesK - 1) / (tilesN * tilesK);
+        const int cap = (total_steps + 7) / 8;
+        if (splitm > cap) splitm = cap;
+        if (splitm < 1) splitm = 1;
+    }
+    if (splitm > total_steps) splitm = total_steps;
+    MADM_REQUIRE(splitm <= 65535 && tilesK <= 65535, "conv2d_wgrad: grid too large");
+    p.steps_per_slice = (total_steps + splitm - 1) / splitm;
+    splitm = (total_steps + p.steps_per_slice - 1) / p.steps_per_slice;
+    dim3 grid((unsigned)tilesN, (unsigned)tilesK, (unsigned)splitm);
+    hipStream_t s = (hipStream_t)stream;
+    if (a->dtype == MADM_BF16) conv2d_wgrad_kernel<bf16_t><<<grid, 256, 0, s>>>(p);
+    else conv2d_wgrad_kernel<float><<<grid, 256, 0, s>>>(p);
+    return madm_check_launch("conv2d_wgrad_kernel");
+}
+
+extern "C" int madm_pack_dgrad_weights(int dtype, const void* w, void* wt, int N, int taps, int C, void* stream) {
+    MADM_REQUIRE(w && wt && N > 0 && taps > 0 && C > 0, "pack_dgrad_weights: bad argument");
+    MADM_REQUIRE(taps <= 65535 && (N + 31) / 32 <= 65535, "pack_dgrad_weights: grid too large");
+    dim3 grid((unsigned)((C + 31) / 32), (unsigned)((N + 31) / 32), (unsigned)taps);
+    MADM_DISPATCH_DTYPE(dtype, (pack_dgrad_weights_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(
+                                   (const T*)w, (T*)wt, N, taps, C)));
+    return madm_check_launch("pack_dgrad_weights_kernel");
+}

@@ -210,6 +210,71 @@ def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=No
                   epilogue=epilogue, out=out, splitk=splitk, alg_nk=alg_nk, stats=stats, out_f32=out_f32)
 
 
+def conv2d_wgrad(x1, dout, B, IH, IW, *, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
+                 upsample=False, dw=None, splitm=0):
+    """Weight gradient of :func:`conv2d` (torch autograd in the reference, engine/train_loop.py:203-217):
+    dw[n][(kh, kw, c)] += sum_m dout[m][n] * A(m, k).  x1 / x2: the tensors the forward conv read; dout: [B*OH*OW, N];
+    dw: f32 [N, KH*KW*(C1+C2)], ACCUMULATED into (a zeroed one is created when None)."""
+    _need_cuda(x1, x2, dout, dw)
+    C1 = x1.shape[1]
+    C2 = 0 if x2 is None else x2.shape[1]
+    N = dout.shape[1]
+    if OH is None:
+        OH = IH * (2 if upsample else 1)
+        OW = IW * (2 if upsample else 1)
+    assert x1.stride(1) == 1 and x1.shape[0] == B * IH * IW, (x1.shape, B, IH, IW)
+    assert x2 is None or (x2.stride(1) == 1 and x2.shape[0] == x1.shape[0] and x2.dtype == x1.dtype)
+    assert dout.dtype == x1.dtype and dout.stride(1) == 1 and dout.shape[0] == B * OH * OW, (dout.shape, B, OH, OW)
+    K = KH * KW * (C1 + C2)
+    if dw is None:
+        dw = torch.zeros((N, K), dtype=torch.float32, device=x1.device)
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and tuple(dw.shape) == (N, K)
+    a = _lib.Conv2dWgradArgs()
+    a.dtype = dtype_code(x1)
+    a.in1 = x1.data_ptr()
+    a.in2 = x2.data_ptr() if x2 is not None else None
+    a.C1, a.C2 = C1, C2
+    a.ld1 = x1.stride(0)
+    a.ld2 = x2.stride(0) if x2 is not None else 0
+    a.dout, a.ldd = dout.data_ptr(), dout.stride(0)
+    a.dw = dw.data_ptr()
+    a.B, a.IH, a.IW, a.OH, a.OW = B, IH, IW, OH, OW
+    a.KH, a.KW, a.stride, a.pad_t, a.pad_l = KH, KW, stride, pad_t, pad_l
+    a.upsample = 1 if upsample else 0
+    a.N = N
+    a.splitm = int(splitm)
+    if PROFILE is None:
+        check(lib.madm_conv2d_wgrad(ctypes.byref(a), _stream()), "madm_conv2d_wgrad")
+    else:
+        es = x1.element_size()
+        nbytes = B * IH * IW * (C1 + C2) * es + dout.numel() * es + dw.numel() * 4
+        with _Prof("conv2d_wgrad" + ("_f32" if x1.dtype == torch.float32 else "_bf16"), 2.0 * dout.shape[0] * N * K,
+                   f"M{dout.shape[0]} N{N} K{K} k{KH} s{stride}", nbytes):
+            check(lib.madm_conv2d_wgrad(ctypes.byref(a), _stream()), "madm_conv2d_wgrad")
+    return dw
+
+
+def pack_dgrad_weights(w, taps):
+    """w [N, taps*C] (the packed forward layout) -> wt [C, taps*N] with the taps reversed: the weights with which
+    :func:`conv2d` applied to dout (pad' = K - 1 - pad) computes the data gradient of a stride-1 conv / linear."""
+    _need_cuda(w)
+    N, K = w.shape
+    assert w.is_contiguous() and K % taps == 0
+    C = K // taps
+    wt = torch.empty((C, taps * N), dtype=w.dtype, device=w.device)
+    check(lib.madm_pack_dgrad_weights(dtype_code(w), w.data_ptr(), wt.data_ptr(), N, taps, C, _stream()),
+          "madm_pack_dgrad_weights")
+    return wt
+
+
+def conv2d_dgrad(dout, wt, B, OH, OW, *, C, KH=1, KW=1, pad_t=0, pad_l=0, out=None, residual=None, splitk=None):
+    """Data gradient of a STRIDE-1 conv2d / linear whose output has the input's spatial size: the forward kernel on
+    dout [B*OH*OW, N] with the repacked weights ``wt = pack_dgrad_weights(w, KH*KW)``; returns din [B*OH*OW, C]
+    (+ residual: the gradient that reaches the same tensor through a skip connection)."""
+    return conv2d(dout, wt, B, OH, OW, N=C, KH=KH, KW=KW, pad_t=KH - 1 - pad_t, pad_l=KW - 1 - pad_l, OH=OH, OW=OW,
+                  out=out, residual=residual, splitk=splitk)
+
+
 def softmax_rows(s, dtype, scale):
     """softmax(scale * s) over the last dim of the f32 logits [rows, L] -> [rows, L] of ``dtype``."""
     _need_cuda(s)

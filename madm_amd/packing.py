@@ -32,6 +32,21 @@ def pack_conv_weight(w, dtype, ktile, splits=None):
     return wp.reshape(N, -1).to(dtype).contiguous()
 
 
+def unpack_conv_weight_grad(dw, Cin, KH, KW, ktile, splits=None):
+    """Inverse of :func:`pack_conv_weight` for the f32 gradient ops.conv2d_wgrad returns:
+    [N, KH*KW*sum(pad(splits))] -> [N, Cin, KH, KW] (the gradient of the padding channels is dropped)."""
+    N = dw.shape[0]
+    if splits is None:
+        splits = [Cin]
+    cpads = [round_up(c, ktile) for c in splits]
+    g = dw.reshape(N, KH, KW, sum(cpads))
+    parts, p0 = [], 0
+    for c, cp in zip(splits, cpads):
+        parts.append(g[..., p0:p0 + c])
+        p0 += cp
+    return torch.cat(parts, dim=-1).permute(0, 3, 1, 2).contiguous()
+
+
 def pack_linear_weight(w, dtype, ktile):
     """w: [N, K] (nn.Linear) -> [N, pad(K)]."""
     N, K = w.shape

@@ -248,6 +248,113 @@ def test_conv_fused_groupnorm_input(cuda, dtype, case):
     assert e < (3e-5 if dtype == torch.float32 else 2e-2), f"{e:.3e} {l2:.3e}"
 
 
+WGRAD_CASES = [
+    # name, B, Cin(list), H, W, Cout, KH, stride, pad_mode, upsample, splitm
+    ("3x3_s1", 2, [64], 8, 8, 64, 3, 1, "same", False, 0),
+    ("3x3_s1_wide", 2, [128], 16, 32, 256, 3, 1, "same", False, 0),
+    ("3x3_s1_ragged", 1, [64], 5, 7, 320, 3, 1, "same", False, 1),
+    ("3x3_s1_sliced", 2, [64], 12, 20, 68, 3, 1, "same", False, 7),
+    ("3x3_s2_unet", 2, [64], 16, 16, 128, 3, 2, "same", False, 0),
+    ("3x3_s2_vae_asym", 2, [64], 16, 16, 128, 3, 2, "asym", False, 3),
+    ("3x3_upsample", 2, [64], 6, 6, 64, 3, 1, "same", True, 0),
+    ("3x3_concat", 2, [128, 64], 8, 8, 192, 3, 1, "same", False, 0),
+    ("3x3_tiny_cin", 1, [4], 16, 16, 128, 3, 1, "same", False, 0),
+    ("3x3_tiny_cout", 2, [64], 8, 8, 4, 3, 1, "same", False, 0),
+    ("1x1", 2, [128], 8, 8, 64, 1, 1, "none", False, 0),
+    ("linear_lora", 1, [320, 64], 77, 1, 320, 1, 1, "none", False, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv2d_wgrad(cuda, dtype, case):
+    """madm_conv2d_wgrad equals torch autograd's weight gradient of the same conv (the reference's backward is
+    loss.backward(), engine/train_loop.py:203-217), for every geometry the forward kernel supports; a second call
+    accumulates."""
+    from madm_amd import ops, packing
+    name, B, cins, H, W, Cout, KH, stride, pad_mode, ups, splitm = case
+    kt = ops.k_tile(dtype)
+    xs = [_q(_gen((B, c, H, W), 30 + i), dtype) for i, c in enumerate(cins)]
+    Cin = sum(cins)
+    w = (_gen((Cout, Cin, KH, KH), 3) / math.sqrt(Cin * KH * KH)).requires_grad_(True)
+    x = torch.cat(xs, 1)
+    if ups:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    if pad_mode == "same":
+        y = F.conv2d(x, w, None, stride=stride, padding=KH // 2)
+        pad_t = pad_l = KH // 2
+    elif pad_mode == "asym":
+        y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, None, stride=stride, padding=0)
+        pad_t = pad_l = 0
+    else:
+        y = F.conv2d(x, w, None, stride=stride, padding=0)
+        pad_t = pad_l = 0
+    OH, OW = y.shape[2], y.shape[3]
+    dy = _q(_gen(tuple(y.shape), 7), dtype)
+    y.backward(dy)
+    ref = w.grad
+
+    cpads = [packing.round_up(c, kt) for c in cins]
+    toks = [to_tokens(xi, dtype, cp) for xi, cp in zip(xs, cpads)]
+    dw = ops.conv2d_wgrad(toks[0], to_tokens(dy, dtype), B, H, W, x2=toks[1] if len(toks) > 1 else None, KH=KH, KW=KH,
+                          stride=stride, pad_t=pad_t, pad_l=pad_l, OH=OH, OW=OW, upsample=ups, splitm=splitm)
+    torch.cuda.synchronize()
+    got = packing.unpack_conv_weight_grad(dw.cpu(), Cin, KH, KH, kt, splits=cins)
+    e, l2 = rel_err(got, ref)
+    # same operands, f32 accumulation in both modes: only the summation order differs
+    assert e < 2e-5, f"{name}: max rel err {e:.3e} l2 {l2:.3e}"
+    # the gradient of the padding channels is exactly zero
+    assert float(dw.abs().sum()) == pytest.approx(float(got.abs().sum()), rel=1e-5)
+    ops.conv2d_wgrad(toks[0], to_tokens(dy, dtype), B, H, W, x2=toks[1] if len(toks) > 1 else None, KH=KH, KW=KH,
+                     stride=stride, pad_t=pad_t, pad_l=pad_l, OH=OH, OW=OW, upsample=ups, splitm=splitm, dw=dw)
+    e2, _ = rel_err(packing.unpack_conv_weight_grad(dw.cpu(), Cin, KH, KH, kt, splits=cins), 2 * ref)
+    assert e2 < 2e-5, f"{name}: accumulation {e2:.3e}"
+
+
+DGRAD_CASES = [
+    # name, B, Cin(list), H, W, Cout, KH
+    ("3x3", 2, [64], 8, 8, 128, 3),
+    ("3x3_ragged", 1, [128], 5, 7, 64, 3),
+    ("3x3_concat", 2, [128, 64], 8, 16, 192, 3),
+    ("1x1", 2, [128], 8, 8, 64, 1),
+    ("linear", 1, [320], 77, 1, 1280, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", DGRAD_CASES, ids=[c[0] for c in DGRAD_CASES])
+def test_conv2d_dgrad(cuda, dtype, case):
+    """The forward kernel on dout with madm_pack_dgrad_weights' transposed / tap-reversed weights equals torch
+    autograd's input gradient of a stride-1 conv / linear (+ the gradient arriving through a skip connection)."""
+    from madm_amd import ops, packing
+    name, B, cins, H, W, Cout, KH = case
+    kt = ops.k_tile(dtype)
+    Cin = sum(cins)
+    x = _gen((B, Cin, H, W), 40).requires_grad_(True)
+    w = _q(_gen((Cout, Cin, KH, KH), 3) / math.sqrt(Cin * KH * KH), dtype)
+    y = F.conv2d(x, w, None, padding=KH // 2)
+    dy = _q(_gen(tuple(y.shape), 8), dtype)
+    skip = _q(_gen((B, Cin, H, W), 9), dtype)
+    y.backward(dy)
+    ref = x.grad + skip
+
+    cpads = [packing.round_up(c, kt) for c in cins]
+    wp = packing.pack_conv_weight(w, dtype, kt, splits=cins).cuda()
+    wt = ops.pack_dgrad_weights(wp, KH * KH)
+    assert tuple(wt.shape) == (sum(cpads), KH * KH * Cout)
+    skip_tok = torch.cat([to_tokens(s_, dtype, cp) for s_, cp in zip(torch.split(skip, cins, 1), cpads)], 1)
+    din = ops.conv2d_dgrad(to_tokens(dy, dtype), wt, B, H, W, C=sum(cpads), KH=KH, KW=KH, pad_t=KH // 2,
+                           pad_l=KH // 2, residual=skip_tok)
+    torch.cuda.synchronize()
+    got = from_tokens(din, B, H, W)
+    parts, p0 = [], 0
+    for c, cp in zip(cins, cpads):
+        parts.append(got[:, p0:p0 + c])
+        p0 += cp
+    e, l2 = rel_err(torch.cat(parts, 1), ref)
+    assert e < TOL[dtype], f"{name}: max rel err {e:.3e} l2 {l2:.3e}"
+
+
 def test_groupnorm_finalize_utility(cuda):
     """madm_groupnorm_finalize (stand-alone form of what the fused conv does in its prologue): x * scale + shift
     equals GroupNorm(x) for a two-source concat whose groups straddle the boundary."""
