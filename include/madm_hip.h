@@ -329,6 +329,27 @@ typedef struct {
 int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream);
 int madm_pack_dgrad_weights(int dtype, const void* w, void* wt, int N, int taps, int C, void* stream);
 
+/* Backward of madm_groupnorm_apply (without its residual input, whose gradient is dz itself) in two passes over
+ * the source x [B*HW][C] occupying channels [c_off, c_off + C) of the Ctot-channel (possibly two-source) tensor; dy
+ * [B*HW][lddy] is the gradient of the whole output (read at column c_off + c), sums1 / C1 / sums2 / gamma / beta /
+ * eps / act exactly as in the forward call:
+ *   bwd_sums : bsums (f64 [B][Ctot][2], zeroed by the caller) [b][c_off + c] += {sum_hw dz, sum_hw dz * xhat},
+ *              dz = dy * act'(z); run it for every source before bwd_apply;
+ *   bwd_apply: dx [B*HW][C] dense = rstd_g * (gamma * dz - mean_g(gamma dz) - xhat * mean_g(gamma dz xhat)), and, when
+ *              dgamma / dbeta (f32 [Ctot], accumulated into) are given, dgamma[c] += sum_b S2, dbeta[c] += sum_b S1.
+ * madm_layernorm_bwd: dx [M][C] of madm_layernorm_fwd; dgamma / dbeta (f32 [C], accumulated into) may both be NULL.
+ * torch autograd in the reference (engine/train_loop.py:203-217) through diffusers' GroupNorm / LayerNorm modules
+ * (ldm_diffusers.py:290,297,299-300,387,435,553,609-610). */
+int madm_groupnorm_bwd_sums(int dtype, const void* x, const void* dy, int lddy, int B, int HW, int C, int c_off, int Ctot,
+                            int G, const double* sums1, int C1, const double* sums2, const float* gamma,
+                            const float* beta, float eps, int act, double* bsums, void* stream);
+int madm_groupnorm_bwd_apply(int dtype, const void* x, const void* dy, int lddy, void* dx, int B, int HW, int C, int c_off,
+                             int Ctot, int G, const double* sums1, int C1, const double* sums2, const float* gamma,
+                             const float* beta, float eps, int act, const double* bsums, float* dgamma, float* dbeta,
+                             void* stream);
+int madm_layernorm_bwd(int dtype, const void* x, const void* dy, void* dx, int M, int C, const float* gamma, float eps,
+                       float* dgamma, float* dbeta, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Training-step tail on ONE flat, 16-byte-aligned fp32 buffer per role (HBM-bound).
  * ------------------------------------------------------------------------------- */

@@ -138,6 +138,13 @@ SYMBOLS = [
     ("madm_nchw_f32_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("madm_conv2d_wgrad", c_int, [ctypes.POINTER(Conv2dWgradArgs), c_void_p]),
     ("madm_pack_dgrad_weights", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    ("madm_groupnorm_bwd_sums", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
+    ("madm_groupnorm_bwd_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
+    ("madm_layernorm_bwd", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p,
+                                   c_void_p, c_void_p]),
 ]
 
 

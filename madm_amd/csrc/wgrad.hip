@@ -182,10 +182,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
         __syncthreads();
     }
 
-    // lane holds dw[n = nb + 4 fg + r][k = kb + fi]: one atomic instruction covers 4 rows x 64 contiguous bytes
+    // lane holds dw[n = nb + 4 fg + r][k = kb + fi]: one instruction covers 4 rows x 64 contiguous bytes.  A single
+    // slice owns its tile of dw: plain read-modify-write (L2 float atomics run at ~0.35 T elements/s, a third of that)
+    const bool owner = gridDim.z == 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + fg * 4;
+        if (owner) {
+            float old[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kc0 + wc * 64 + i * 16 + fi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    old[i][r] = (k < p.K && n + r < p.N) ? p.dw[(size_t)(n + r) * p.K + k] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = kc0 + wc * 64 + i * 16 + fi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k < p.K && n + r < p.N) p.dw[(size_t)(n + r) * p.K + k] = old[i][r] + acc[j][i][r];
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = kc0 + wc * 64 + i * 16 + fi;
@@ -260,9 +280,13 @@ extern "C" int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream) 
     const int total_steps = (p.M + px - 1) / px;
     const int tilesN = (p.N + 127) / 128, tilesK = (p.K + 127) / 128;
     int splitm = a->splitm;
-    if (splitm <= 0) {   // ~4 blocks per CU, at least 8 steps per slice
-        splitm = (1024 + tilesN * tilesK - 1) / (tilesN * tilesK);
-        const int cap = (total_steps + 7) / 8;
+    if (splitm <= 0) {
+        // one round of resident blocks (2 per CU, a little oversubscribed): every further slice only adds a pass of
+        // float atomics over dw (~3 ps per element).  tools/bench_backward.py --sweep: within ~10 % of the best
+        // slice count on the conv / linear shapes of the 512 x 512 forward
+        const int tiles = tilesN * tilesK;
+        splitm = (640 + tiles / 2) / tiles;
+        const int cap = total_steps / 2;
         if (splitm > cap) splitm = cap;
         if (splitm < 1) splitm = 1;
     }

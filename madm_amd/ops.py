@@ -371,6 +371,59 @@ def groupnorm(xs, B, HW, G, gamma, beta, eps, silu=False, stats=None, act=None, 
     return out
 
 
+def groupnorm_backward(xs, dy, B, HW, G, gamma, beta, eps, stats, act=None, dgamma=None, dbeta=None):
+    """Backward of :func:`groupnorm` (without residual): ``xs`` / ``stats`` / gamma / beta / eps / act as in the forward
+    call, dy [B*HW, Ctot] the gradient of its output.  Returns ([dx_i], dgamma, dbeta); dgamma / dbeta (f32 [Ctot]) are
+    accumulated into when given, created zeroed otherwise."""
+    if isinstance(xs, torch.Tensor):
+        xs = [xs]
+    assert 1 <= len(xs) <= 2 and len(stats) == len(xs)
+    _need_cuda(gamma, beta, dy, *xs, *stats)
+    Ctot = sum(x.shape[1] for x in xs)
+    assert dy.dtype == xs[0].dtype and dy.stride(1) == 1 and tuple(dy.shape) == (B * HW, Ctot)
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == Ctot
+    dev = xs[0].device
+    if dgamma is None:
+        dgamma = torch.zeros(Ctot, dtype=torch.float32, device=dev)
+        dbeta = torch.zeros(Ctot, dtype=torch.float32, device=dev)
+    bsums = torch.zeros((B, Ctot, 2), dtype=torch.float64, device=dev)
+    C1 = xs[0].shape[1]
+    s2 = stats[1].data_ptr() if len(xs) > 1 else None
+    code = _act_code(act=act)
+    off = 0
+    for x in xs:
+        assert x.is_contiguous() and x.shape[0] == B * HW
+        check(lib.madm_groupnorm_bwd_sums(dtype_code(x), x.data_ptr(), dy.data_ptr(), dy.stride(0), B, HW, x.shape[1],
+                                          off, Ctot, G, stats[0].data_ptr(), C1, s2, gamma.data_ptr(), beta.data_ptr(),
+                                          float(eps), code, bsums.data_ptr(), _stream()), "madm_groupnorm_bwd_sums")
+        off += x.shape[1]
+    dxs, off = [], 0
+    for x in xs:
+        dx = torch.empty_like(x)
+        check(lib.madm_groupnorm_bwd_apply(dtype_code(x), x.data_ptr(), dy.data_ptr(), dy.stride(0), dx.data_ptr(), B, HW,
+                                           x.shape[1], off, Ctot, G, stats[0].data_ptr(), C1, s2, gamma.data_ptr(),
+                                           beta.data_ptr(), float(eps), code, bsums.data_ptr(), dgamma.data_ptr(),
+                                           dbeta.data_ptr(), _stream()), "madm_groupnorm_bwd_apply")
+        dxs.append(dx)
+        off += x.shape[1]
+    return dxs, dgamma, dbeta
+
+
+def layernorm_backward(x, dy, gamma, eps, dgamma=None, dbeta=None):
+    """Backward of :func:`layernorm`: returns (dx, dgamma, dbeta); dgamma / dbeta f32 [C] are accumulated into when
+    given, created zeroed otherwise."""
+    _need_cuda(x, dy, gamma, dgamma, dbeta)
+    assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape and x.dtype == dy.dtype and x.dim() == 2
+    if dgamma is None:
+        dgamma = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+        dbeta = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    check(lib.madm_layernorm_bwd(dtype_code(x), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.shape[0], x.shape[1],
+                                 gamma.data_ptr(), float(eps), dgamma.data_ptr(), dbeta.data_ptr(), _stream()),
+          "madm_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
 def layernorm(x, gamma, beta, eps, out=None):
     _need_cuda(x, gamma, beta)
     assert x.is_contiguous() and x.dim() == 2

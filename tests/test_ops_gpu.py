@@ -355,6 +355,66 @@ def test_conv2d_dgrad(cuda, dtype, case):
     assert e < TOL[dtype], f"{name}: max rel err {e:.3e} l2 {l2:.3e}"
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, [128], 16, 16, "silu"), (2, [320], 8, 8, "none"), (1, [64], 11, 19, "relu"),
+                                  (2, [128, 64], 8, 16, "silu"), (2, [1280, 640], 4, 6, "silu")],
+                         ids=["silu", "plain_cpg10", "relu_ragged", "concat", "concat_straddle"])
+def test_groupnorm_backward(cuda, dtype, case):
+    """madm_groupnorm_bwd_sums / _apply equal torch autograd through act(F.group_norm(cat(xs))) for dx of every source,
+    dgamma and dbeta (groups may straddle the boundary of a two-source concat)."""
+    from madm_amd import ops
+    B, cins, H, W, act = case
+    Cin = sum(cins)
+    xs = [_q(_gen((B, c, H, W), 50 + i) * (1.0 + i) + 0.5 * i, dtype).requires_grad_(True) for i, c in enumerate(cins)]
+    gamma = (1.0 + 0.2 * _gen((Cin,), 2)).requires_grad_(True)
+    beta = (0.3 * _gen((Cin,), 3)).requires_grad_(True)
+    y = F.group_norm(torch.cat(xs, 1), 32, gamma, beta, eps=1e-5)
+    y = F.silu(y) if act == "silu" else (F.relu(y) if act == "relu" else y)
+    dy = _q(_gen(tuple(y.shape), 4), dtype)
+    y.backward(dy)
+    toks = [to_tokens(x.detach(), dtype) for x in xs]
+    sts = []
+    for t in toks:
+        st = torch.zeros((B, t.shape[1], 2), dtype=torch.float64, device="cuda")
+        ops.groupnorm_stats(t, B, H * W, st)
+        sts.append(st)
+    dxs, dg, db = ops.groupnorm_backward(toks, to_tokens(dy, dtype), B, H * W, 32, gamma.detach().cuda(),
+                                         beta.detach().cuda(), 1e-5, sts, act=act)
+    torch.cuda.synchronize()
+    tol = 3e-5 if dtype == torch.float32 else 1.5e-2
+    for x, dx in zip(xs, dxs):
+        e, l2 = rel_err(from_tokens(dx, B, H, W), x.grad)
+        assert e < tol, f"dx {e:.3e} {l2:.3e}"
+    assert rel_err(dg.cpu(), gamma.grad)[0] < tol
+    assert rel_err(db.cpu(), beta.grad)[0] < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(77, 320), (1024, 640), (9, 1280), (300, 2560)], ids=["c320", "c640", "c1280", "c2560"])
+def test_layernorm_backward(cuda, dtype, case):
+    """madm_layernorm_bwd equals torch autograd through F.layer_norm (dx, dgamma, dbeta); a second call accumulates
+    the parameter gradients."""
+    from madm_amd import ops
+    M, C = case
+    if dtype == torch.float32 and C > 1280:
+        pytest.skip("f32 rows are limited to 1280 channels (as the forward kernel)")
+    x = _q(_gen((M, C), 60) * 1.5 + 0.3, dtype).requires_grad_(True)
+    gamma = (1.0 + 0.2 * _gen((C,), 2)).requires_grad_(True)
+    beta = (0.3 * _gen((C,), 3)).requires_grad_(True)
+    y = F.layer_norm(x, (C,), gamma, beta, eps=1e-5)
+    dy = _q(_gen((M, C), 5), dtype)
+    y.backward(dy)
+    xd, dyd = x.detach().to(dtype).cuda(), dy.to(dtype).cuda()
+    dx, dg, db = ops.layernorm_backward(xd, dyd, gamma.detach().cuda(), 1e-5)
+    torch.cuda.synchronize()
+    tol = 3e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(dx.float().cpu(), x.grad)[0] < tol
+    assert rel_err(dg.cpu(), gamma.grad)[0] < tol
+    assert rel_err(db.cpu(), beta.grad)[0] < tol
+    ops.layernorm_backward(xd, dyd, gamma.detach().cuda(), 1e-5, dgamma=dg, dbeta=db)
+    assert rel_err(dg.cpu(), 2 * gamma.grad)[0] < tol
+
+
 def test_groupnorm_finalize_utility(cuda):
     """madm_groupnorm_finalize (stand-alone form of what the fused conv does in its prologue): x * scale + shift
     equals GroupNorm(x) for a two-source concat whose groups straddle the boundary."""
