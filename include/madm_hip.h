@@ -336,7 +336,9 @@ int madm_pack_dgrad_weights(int dtype, const void* w, void* wt, int N, int taps,
  *   bwd_sums : bsums (f64 [B][Ctot][2], zeroed by the caller) [b][c_off + c] += {sum_hw dz, sum_hw dz * xhat},
  *              dz = dy * act'(z); run it for every source before bwd_apply;
  *   bwd_apply: dx [B*HW][C] dense = rstd_g * (gamma * dz - mean_g(gamma dz) - xhat * mean_g(gamma dz xhat)), and, when
- *              dgamma / dbeta (f32 [Ctot], accumulated into) are given, dgamma[c] += sum_b S2, dbeta[c] += sum_b S1.
+ *              dgamma / dbeta (f32 [Ctot], accumulated into) are given, dgamma[c] += sum_b S2, dbeta[c] += sum_b S1;
+ *              dres (NULL or [B*HW][lddres], read at column c_off + c) is added to dx: the gradient that reaches x
+ *              through a skip path (ResnetBlock2D's shortcut).
  * madm_layernorm_bwd: dx [M][C] of madm_layernorm_fwd; dgamma / dbeta (f32 [C], accumulated into) may both be NULL.
  * torch autograd in the reference (engine/train_loop.py:203-217) through diffusers' GroupNorm / LayerNorm modules
  * (ldm_diffusers.py:290,297,299-300,387,435,553,609-610). */
@@ -346,7 +348,7 @@ int madm_groupnorm_bwd_sums(int dtype, const void* x, const void* dy, int lddy, 
 int madm_groupnorm_bwd_apply(int dtype, const void* x, const void* dy, int lddy, void* dx, int B, int HW, int C, int c_off,
                              int Ctot, int G, const double* sums1, int C1, const double* sums2, const float* gamma,
                              const float* beta, float eps, int act, const double* bsums, float* dgamma, float* dbeta,
-                             void* stream);
+                             const void* dres, int lddres, void* stream);
 int madm_layernorm_bwd(int dtype, const void* x, const void* dy, void* dx, int M, int C, const float* gamma, float eps,
                        float* dgamma, float* dbeta, void* stream);
 

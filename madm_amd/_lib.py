@@ -142,7 +142,7 @@ SYMBOLS = [
                                         c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     ("madm_groupnorm_bwd_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p,
-                                         c_void_p, c_void_p, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     ("madm_layernorm_bwd", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p,
                                    c_void_p, c_void_p]),
 ]

@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const double* __restrict__ sums2,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float eps, int act, const double* __restrict__ bsums,
-                                                           float* dgamma, float* dbeta) {
+                                                           float* dgamma, float* dbeta, const T* __restrict__ dres,
+                                                           int lddres) {
     constexpr int EPC = TT<T>::EPC;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // r, mr, gamma, beta, kA, kB [C]
     float* r = lds;
@@ -188,19 +189,23 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     const T* xb = x + (size_t)b * HW * C;
     const T* db = dy + (size_t)b * HW * lddy + c_off;
     T* ob = dx + (size_t)b * HW * C;
+    const T* rb = dres ? dres + (size_t)b * HW * lddres + c_off : nullptr;
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const unsigned row = idx / CPR, q = idx - row * CPR;
         const uint4 xv = *reinterpret_cast<const uint4*>(xb + (size_t)idx * EPC);
         const uint4 dv = *reinterpret_cast<const uint4*>(db + (size_t)row * lddy + q * EPC);
-        float xf[EPC], df[EPC], o[EPC];
+        float xf[EPC], df[EPC], o[EPC], rf[EPC];
         chunk_to_f32<T>(xv, xf);
         chunk_to_f32<T>(dv, df);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) rf[j] = 0.f;
+        if (rb) chunk_to_f32<T>(*reinterpret_cast<const uint4*>(rb + (size_t)row * lddres + q * EPC), rf);
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
             const int c = q * EPC + j;
             const float xh = xf[j] * r[c] + mr[c];
             const float dz = act_grad_f(xh * gm[c] + bt[c], df[j], act);
-            o[j] = r[c] * (gm[c] * dz - kA[c] - xh * kB[c]);
+            o[j] = r[c] * (gm[c] * dz - kA[c] - xh * kB[c]) + rf[j];
         }
         *reinterpret_cast<uint4*>(ob + (size_t)idx * EPC) = f32_to_chunk<T>(o);
     }
@@ -351,12 +356,13 @@ int madm_groupnorm_bwd_sums(int dtype, const void* x, const void* dy, int lddy, 
 int madm_groupnorm_bwd_apply(int dtype, const void* x, const void* dy, int lddy, void* dx, int B, int HW, int C, int c_off,
                              int Ctot, int G, const double* sums1, int C1, const double* sums2, const float* gamma,
                              const float* beta, float eps, int act, const double* bsums, float* dgamma, float* dbeta,
-                             void* stream) {
+                             const void* dres, int lddres, void* stream) {
     const int rc = gn_bwd_check(dtype, x, dy, lddy, B, HW, C, c_off, Ctot, G, sums1, C1, sums2, gamma, beta, bsums,
                                 (size_t)6 * C);
     if (rc != MADM_OK) return rc;
     MADM_REQUIRE(dx && (!dgamma == !dbeta), "groupnorm_bwd_apply: dx missing or only one of dgamma / dbeta given");
     const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(!dres || lddres % epc == 0, "groupnorm_bwd_apply: lddres must be a multiple of %d elements", epc);
     const long long total = (long long)HW * (C / epc);
     int strips = (int)((total + 256 * 4 - 1) / (256 * 4));
     const int want = (4096 + B - 1) / B;
@@ -367,7 +373,7 @@ int madm_groupnorm_bwd_apply(int dtype, const void* x, const void* dy, int lddy,
     hipStream_t s = (hipStream_t)stream;
     MADM_DISPATCH_DTYPE(dtype, (gn_bwd_apply_kernel<T><<<grid, 256, lds, s>>>(
                                    (const T*)x, (const T*)dy, lddy, (T*)dx, HW, C, c_off, Ctot, G, sums1, C1, sums2, gamma,
-                                   beta, eps, act, bsums, dgamma, dbeta)));
+                                   beta, eps, act, bsums, dgamma, dbeta, (const T*)dres, lddres)));
     return madm_check_launch("gn_bwd_apply_kernel");
 }
 

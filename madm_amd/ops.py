@@ -371,13 +371,15 @@ def groupnorm(xs, B, HW, G, gamma, beta, eps, silu=False, stats=None, act=None, 
     return out
 
 
-def groupnorm_backward(xs, dy, B, HW, G, gamma, beta, eps, stats, act=None, dgamma=None, dbeta=None):
+def groupnorm_backward(xs, dy, B, HW, G, gamma, beta, eps, stats, act=None, dgamma=None, dbeta=None, dres=None):
     """Backward of :func:`groupnorm` (without residual): ``xs`` / ``stats`` / gamma / beta / eps / act as in the forward
     call, dy [B*HW, Ctot] the gradient of its output.  Returns ([dx_i], dgamma, dbeta); dgamma / dbeta (f32 [Ctot]) are
-    accumulated into when given, created zeroed otherwise."""
+    accumulated into when given, created zeroed otherwise.  ``dres`` [B*HW, Ctot]: a gradient reaching the same
+    (concatenated) input through a skip path, added to the dx_i."""
     if isinstance(xs, torch.Tensor):
         xs = [xs]
     assert 1 <= len(xs) <= 2 and len(stats) == len(xs)
+    assert dres is None or (dres.dtype == dy.dtype and dres.stride(1) == 1 and dres.shape == dy.shape and dres.is_cuda)
     _need_cuda(gamma, beta, dy, *xs, *stats)
     Ctot = sum(x.shape[1] for x in xs)
     assert dy.dtype == xs[0].dtype and dy.stride(1) == 1 and tuple(dy.shape) == (B * HW, Ctot)
@@ -403,7 +405,8 @@ def groupnorm_backward(xs, dy, B, HW, G, gamma, beta, eps, stats, act=None, dgam
         check(lib.madm_groupnorm_bwd_apply(dtype_code(x), x.data_ptr(), dy.data_ptr(), dy.stride(0), dx.data_ptr(), B, HW,
                                            x.shape[1], off, Ctot, G, stats[0].data_ptr(), C1, s2, gamma.data_ptr(),
                                            beta.data_ptr(), float(eps), code, bsums.data_ptr(), dgamma.data_ptr(),
-                                           dbeta.data_ptr(), _stream()), "madm_groupnorm_bwd_apply")
+                                           dbeta.data_ptr(), _ptr(dres), dres.stride(0) if dres is not None else 0,
+                                           _stream()), "madm_groupnorm_bwd_apply")
         dxs.append(dx)
         off += x.shape[1]
     return dxs, dgamma, dbeta
