@@ -328,6 +328,15 @@ typedef struct {
 } madm_conv2d_wgrad_args;
 int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream);
 int madm_pack_dgrad_weights(int dtype, const void* w, void* wt, int N, int taps, int C, void* stream);
+/* Data gradient of the other two conv geometries, reduced to the stride-1 case:
+ *   stride-2 conv (UNet Downsample2D pad 1, VAE Downsample2D pad (0,1,0,1)): y [B][H][W][C] = dout [B][OH][OW][C]
+ *     zero-inserted (y[2 oy][2 ox] = dout[oy][ox], 0 elsewhere), then the stride-1 data gradient with pad' = 2 - pad;
+ *   nearest-2x upsample + conv (Upsample2D): the stride-1 data gradient at the upsampled size, then
+ *     madm_sumpool2x2: y [B][H][W][C] = sum of the 2 x 2 blocks of x [B][2H][2W][C].
+ * madm_silu_bwd: dx = dy * silu'(x) (time-embedding activation, ResnetBlock2D's silu(temb)). */
+int madm_zero_insert2x(int dtype, const void* x, void* y, int B, int OH, int OW, int H, int W, int C, void* stream);
+int madm_sumpool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream);
+int madm_silu_bwd(int dtype, const void* x, const void* dy, void* dx, size_t n, void* stream);
 
 /* Backward of madm_groupnorm_apply (without its residual input, whose gradient is dz itself) in two passes over
  * the source x [B*HW][C] occupying channels [c_off, c_off + C) of the Ctot-channel (possibly two-source) tensor; dy

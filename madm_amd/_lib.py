@@ -138,6 +138,9 @@ SYMBOLS = [
     ("madm_nchw_f32_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("madm_conv2d_wgrad", c_int, [ctypes.POINTER(Conv2dWgradArgs), c_void_p]),
     ("madm_pack_dgrad_weights", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    ("madm_zero_insert2x", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    ("madm_sumpool2x2", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    ("madm_silu_bwd", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     ("madm_groupnorm_bwd_sums", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     ("madm_groupnorm_bwd_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -7,9 +7,9 @@ a module is an explicit function over the same channels-last ``Tok`` tensors its
 holds), which is also how the 288 GB budget would be spent at bs = 2: no activation stash at all.
 
 Parameter gradients come back as ``{parameter name: f32 tensor in the nn.Parameter's own shape}`` -- what a
-``FlatParams`` gradient buffer (madm_amd/optim.py) takes.  Built so far: Conv2d (stride 1), Linear, GroupNorm(+act),
-LayerNorm and diffusers' ResnetBlock2D (ldm_diffusers.py:290,333,387,435 call sites); the transformer blocks (attention
-backward), the stride-2 / upsample convs and the autograd wiring of the whole UNet are not.
+``FlatParams`` gradient buffer (madm_amd/optim.py) takes.  Built so far: Conv2d (stride 1 / stride 2 with both paddings /
+nearest-2x upsample), Linear, GroupNorm(+act), LayerNorm and diffusers' ResnetBlock2D (ldm_diffusers.py:290,333,387,435
+call sites); the transformer blocks (attention backward) and the autograd wiring of the whole UNet are not.
 """
 import torch
 
@@ -25,28 +25,39 @@ def _colsum_per_image(t, B, HW):
     return sums[:, :, 0].float()
 
 
-def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None):
-    """Gradients of ``conv(x, x2)`` (plain conv: the caller handles a fused norm) for a stride-1 ``nn.Conv2d`` twin:
-    returns (dx_cat Tok-tensor [M, C1(+C2)] or None, {"weight": ..., "bias": ...}).  ``dres`` is added to dx."""
-    assert conv.stride == 1 and not conv.asym_pad, "stride-2 data gradients are not built yet"
+def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None, upsample=False):
+    """Gradients of ``conv(x, x2, upsample=...)`` (plain conv: the caller handles a fused norm) for the ``nn.Conv2d``
+    twin ``conv``: returns (dx_cat [M_in, C1(+C2)] or None, {"weight": ..., "bias": ...}).  ``dres`` (stride-1 layers)
+    is added to dx.  Stride-2 layers (Downsample2D, both paddings) run the stride-1 data gradient on the zero-inserted
+    ``dout``; the nearest-2x upsample conv (Upsample2D) runs it at the upsampled size and sum-pools 2 x 2."""
     dtype = x.t.dtype
     kt = ops.k_tile(dtype)
     k = conv.kernel_size
+    pad = 0 if conv.asym_pad else conv.padding
+    OH, OW = conv.out_hw(x.H, x.W, upsample)
     splits = None if x2 is None else [x.C, x2.C]
-    dwp = ops.conv2d_wgrad(x.t, dout, x.B, x.H, x.W, x2=None if x2 is None else x2.t, KH=k, KW=k, pad_t=conv.padding,
-                           pad_l=conv.padding)
-    cins = splits if splits is not None else [conv.in_channels]
-    assert sum(cins) == conv.in_channels or (x2 is None and x.C == packing.round_up(conv.in_channels, kt))
+    dwp = ops.conv2d_wgrad(x.t, dout, x.B, x.H, x.W, x2=None if x2 is None else x2.t, KH=k, KW=k, stride=conv.stride,
+                           pad_t=pad, pad_l=pad, OH=OH, OW=OW, upsample=upsample)
     dw = packing.unpack_conv_weight_grad(dwp[:conv.out_channels], conv.in_channels, k, k, kt, splits=splits)
     grads = {"weight": dw}
     if conv.bias is not None:
-        grads["bias"] = _colsum_per_image(dout, x.B, dout.shape[0] // x.B).sum(0)[:conv.out_channels]
+        grads["bias"] = _colsum_per_image(dout, x.B, OH * OW).sum(0)[:conv.out_channels]
     dx = None
     if need_dx:
         wp, _ = conv.packed(dtype, splits)
         wt = ops.pack_dgrad_weights(wp, k * k)
-        dx = ops.conv2d_dgrad(dout, wt, x.B, x.H, x.W, C=wt.shape[0], KH=k, KW=k, pad_t=conv.padding,
-                              pad_l=conv.padding, residual=dres)
+        if conv.stride == 1 and not upsample:
+            dx = ops.conv2d_dgrad(dout, wt, x.B, x.H, x.W, C=wt.shape[0], KH=k, KW=k, pad_t=pad, pad_l=pad, residual=dres)
+        elif conv.stride == 2 and not upsample:
+            assert dres is None
+            dz = ops.zero_insert2x(dout, x.B, OH, OW, x.H, x.W)
+            dx = ops.conv2d_dgrad(dz, wt, x.B, x.H, x.W, C=wt.shape[0], KH=k, KW=k, pad_t=pad, pad_l=pad)
+        elif conv.stride == 1 and upsample:
+            assert dres is None
+            du = ops.conv2d_dgrad(dout, wt, x.B, OH, OW, C=wt.shape[0], KH=k, KW=k, pad_t=pad, pad_l=pad)
+            dx = ops.sumpool2x2(du, x.B, x.H, x.W)
+        else:
+            raise NotImplementedError(f"data gradient of stride {conv.stride} upsample {upsample}")
     return dx, grads
 
 

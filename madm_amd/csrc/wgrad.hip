@@ -238,7 +238,98 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(const T* __rest
     }
 }
 
+// y[b][iy][ix][:] = x[b][iy / 2][ix / 2][:] on even (iy, ix) inside the source, 0 elsewhere (16-byte chunks): the
+// zero-inserted output gradient that turns the data gradient of a stride-2 conv into a stride-1 one
+template <typename T>
+__global__ __launch_bounds__(256) void zero_insert2x_kernel(const uint4* __restrict__ x, uint4* __restrict__ y, int OH,
+                                                            int OW, int H, int W, int CPR, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % CPR);
+        size_t pix = i / CPR;
+        const int ix = (int)(pix % W);
+        pix /= W;
+        const int iy = (int)(pix % H), b = (int)(pix / H);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (!(iy & 1) && !(ix & 1) && (iy >> 1) < OH && (ix >> 1) < OW)
+            v = x[(((size_t)b * OH + (iy >> 1)) * OW + (ix >> 1)) * CPR + q];
+        y[i] = v;
+    }
+}
+
+// y[b][iy][ix][:] = sum of the 2 x 2 block x[b][2 iy + {0, 1}][2 ix + {0, 1}][:] (f32 sum): the gradient of a
+// nearest-2x upsample
+template <typename T>
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C,
+                                                         size_t total) {
+    constexpr int EPC = TT<T>::EPC;
+    const int CPR = C / EPC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % CPR);
+        size_t pix = i / CPR;
+        const int ix = (int)(pix % W);
+        pix /= W;
+        const int iy = (int)(pix % H), b = (int)(pix / H);
+        const T* src = x + ((((size_t)b * 2 * H + 2 * iy) * 2 * W) + 2 * ix) * C + q * EPC;
+        float a[EPC], f[EPC];
+        chunk_to_f32<T>(*reinterpret_cast<const uint4*>(src), a);
+        chunk_to_f32<T>(*reinterpret_cast<const uint4*>(src + C), f);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) a[j] += f[j];
+        chunk_to_f32<T>(*reinterpret_cast<const uint4*>(src + (size_t)2 * W * C), f);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) a[j] += f[j];
+        chunk_to_f32<T>(*reinterpret_cast<const uint4*>(src + (size_t)2 * W * C + C), f);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) a[j] += f[j];
+        *reinterpret_cast<uint4*>(y + i * EPC) = f32_to_chunk<T>(a);
+    }
+}
+
+// dx = dy * silu'(x)
+template <typename T>
+__global__ void silu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float z = TT<T>::ld(x + i);
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+        TT<T>::st(dx + i, TT<T>::ld(dy + i) * sg * (1.0f + z * (1.0f - sg)));
+    }
+}
+
+unsigned bwd_grid_for(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (unsigned)(b > 16384 ? 16384 : (b ? b : 1));
+}
+
 }  // namespace
+
+extern "C" int madm_zero_insert2x(int dtype, const void* x, void* y, int B, int OH, int OW, int H, int W, int C,
+                                  void* stream) {
+    MADM_REQUIRE(x && y && B > 0 && OH > 0 && OW > 0 && H > 0 && W > 0 && C > 0, "zero_insert2x: bad argument");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(dtype == MADM_F32 || dtype == MADM_BF16, "zero_insert2x: unknown dtype %d", dtype);
+    MADM_REQUIRE(C % epc == 0, "zero_insert2x: C = %d must be a multiple of %d", C, epc);
+    const size_t total = (size_t)B * H * W * (C / epc);
+    zero_insert2x_kernel<float><<<bwd_grid_for(total), 256, 0, (hipStream_t)stream>>>((const uint4*)x, (uint4*)y, OH, OW, H,
+                                                                                      W, C / epc, total);
+    return madm_check_launch("zero_insert2x_kernel");
+}
+
+extern "C" int madm_sumpool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream) {
+    MADM_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "sumpool2x2: bad argument");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(C % epc == 0, "sumpool2x2: C = %d must be a multiple of %d", C, epc);
+    const size_t total = (size_t)B * H * W * (C / epc);
+    MADM_DISPATCH_DTYPE(dtype, (sumpool2x2_kernel<T><<<bwd_grid_for(total), 256, 0, (hipStream_t)stream>>>(
+                                   (const T*)x, (T*)y, H, W, C, total)));
+    return madm_check_launch("sumpool2x2_kernel");
+}
+
+extern "C" int madm_silu_bwd(int dtype, const void* x, const void* dy, void* dx, size_t n, void* stream) {
+    MADM_REQUIRE(x && dy && dx && n > 0, "silu_bwd: bad argument");
+    MADM_DISPATCH_DTYPE(dtype, (silu_bwd_kernel<T><<<bwd_grid_for(n), 256, 0, (hipStream_t)stream>>>(
+                                   (const T*)x, (const T*)dy, (T*)dx, n)));
+    return madm_check_launch("silu_bwd_kernel");
+}
 
 extern "C" int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream) {
     MADM_REQUIRE(a && a->in1 && a->dout && a->dw, "conv2d_wgrad: null argument");

@@ -275,6 +275,35 @@ def conv2d_dgrad(dout, wt, B, OH, OW, *, C, KH=1, KW=1, pad_t=0, pad_l=0, out=No
                   out=out, residual=residual, splitk=splitk)
 
 
+def zero_insert2x(dout, B, OH, OW, H, W):
+    """[B*OH*OW, C] -> [B*H*W, C] with dout at the even positions and zeros elsewhere (stride-2 data gradient)."""
+    _need_cuda(dout)
+    assert dout.is_contiguous() and dout.shape[0] == B * OH * OW
+    y = torch.empty((B * H * W, dout.shape[1]), dtype=dout.dtype, device=dout.device)
+    check(lib.madm_zero_insert2x(dtype_code(dout), dout.data_ptr(), y.data_ptr(), B, OH, OW, H, W, dout.shape[1],
+                                 _stream()), "madm_zero_insert2x")
+    return y
+
+
+def sumpool2x2(x, B, H, W):
+    """[B*2H*2W, C] -> [B*H*W, C]: sums of the 2 x 2 blocks (gradient of the nearest-2x upsample)."""
+    _need_cuda(x)
+    assert x.is_contiguous() and x.shape[0] == B * 4 * H * W
+    y = torch.empty((B * H * W, x.shape[1]), dtype=x.dtype, device=x.device)
+    check(lib.madm_sumpool2x2(dtype_code(x), x.data_ptr(), y.data_ptr(), B, H, W, x.shape[1], _stream()),
+          "madm_sumpool2x2")
+    return y
+
+
+def silu_backward(x, dy):
+    _need_cuda(x, dy)
+    assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape and x.dtype == dy.dtype
+    dx = torch.empty_like(x)
+    check(lib.madm_silu_bwd(dtype_code(x), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()),
+          "madm_silu_bwd")
+    return dx
+
+
 def softmax_rows(s, dtype, scale):
     """softmax(scale * s) over the last dim of the f32 logits [rows, L] -> [rows, L] of ``dtype``."""
     _need_cuda(s)

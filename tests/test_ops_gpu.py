@@ -476,6 +476,50 @@ def test_resnet_block_backward(cuda, dtype, case):
         assert e < tol, f"{name}: {e:.3e} {l2:.3e}"
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [("s1", 64, 128, 8, 12, 1, 1, False, False), ("s2_unet", 64, 64, 16, 16, 2, 1, False, False),
+                                  ("s2_vae_asym", 128, 128, 16, 12, 2, 0, True, False),
+                                  ("upsample", 64, 64, 6, 10, 1, 1, False, True), ("1x1", 128, 64, 8, 8, 1, 0, False, False)],
+                         ids=lambda c: c[0])
+def test_conv_module_backward(cuda, dtype, case):
+    """backward.conv2d_backward on the nn.Conv2d twin: weight, bias and data gradients of the stride-1, the two
+    stride-2 (Downsample2D) and the nearest-2x upsample (Upsample2D) geometries equal torch autograd."""
+    from madm_amd import backward
+    from madm_amd.nn import Tok, Conv2d
+    name, Cin, Cout, H, W, stride, padding, asym, ups = case
+    k = 1 if name == "1x1" else 3
+    B = 2
+    conv = Conv2d(Cin, Cout, k, stride=stride, padding=padding, asym_pad=asym).cuda()
+    w = _q(_gen((Cout, Cin, k, k), 1) / math.sqrt(Cin * k * k), dtype).requires_grad_(True)
+    bias = (0.1 * _gen((Cout,), 2)).requires_grad_(True)
+    conv.weight.data.copy_(w.detach())
+    conv.bias.data.copy_(bias.detach())
+    x = _q(_gen((B, Cin, H, W), 3), dtype).requires_grad_(True)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    if asym:
+        xin = F.pad(xin, (0, 1, 0, 1))
+    y = F.conv2d(xin, w, bias, stride=stride, padding=padding)
+    dy = _q(_gen(tuple(y.shape), 4), dtype)
+    y.backward(dy)
+    xt = Tok(to_tokens(x.detach(), dtype), B, H, W)
+    assert tuple(conv.out_hw(H, W, ups)) == tuple(y.shape[2:])
+    dx, grads = backward.conv2d_backward(conv, xt, to_tokens(dy, dtype), upsample=ups)
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    assert rel_err(from_tokens(dx, B, H, W), x.grad)[0] < tol
+    assert rel_err(grads["weight"].cpu(), w.grad)[0] < 2e-5
+    assert rel_err(grads["bias"].cpu(), bias.grad)[0] < 2e-5
+
+
+def test_silu_backward(cuda):
+    from madm_amd import ops
+    x = _gen((64, 1280), 1).requires_grad_(True)
+    dy = _gen((64, 1280), 2)
+    F.silu(x).backward(dy)
+    dx = ops.silu_backward(x.detach().cuda(), dy.cuda())
+    assert rel_err(dx.cpu(), x.grad)[0] < 1e-5
+
+
 def test_groupnorm_finalize_utility(cuda):
     """madm_groupnorm_finalize (stand-alone form of what the fused conv does in its prologue): x * scale + shift
     equals GroupNorm(x) for a two-source concat whose groups straddle the boundary."""
