@@ -189,6 +189,24 @@ typedef struct {
 } madm_attention_args;
 int madm_attention_fwd(const madm_attention_args* a, void* stream);
 
+/* Backward of madm_attention_fwd (torch autograd through F.scaled_dot_product_attention in the reference,
+ * engine/train_loop.py:203-217): dq / dk / dv (dtype, same addressing as q / k / v with their own row strides) from
+ * q, k, v, the forward output o and its gradient dout.  Nothing is saved by the forward: the row log-sum-exp is
+ * recomputed, together with rowsum(dout * o), into the f32 workspace (2 * B * H * Lq floats).  Two launches (dq, then
+ * dk + dv), no atomics: deterministic.  D in {40, 64, 80, 160}. */
+typedef struct {
+    int dtype;
+    const void* q; const void* k; const void* v; const void* o; const void* dout;
+    void* dq; void* dk; void* dv;
+    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;   /* row strides in elements */
+    int B, H, Lq, Lk, D;
+    float scale;
+    void* workspace;
+    size_t workspace_bytes;
+} madm_attention_bwd_args;
+size_t madm_attention_bwd_workspace_bytes(const madm_attention_bwd_args* a);
+int madm_attention_bwd(const madm_attention_bwd_args* a, void* stream);
+
 /* p[r][:] = softmax(scale * s[r][:]) over L columns: f32 logits [rows][lds] -> dtype [rows][ldp].  With two
  * madm_conv2d_fwd GEMMs (S = Q K^T with out_f32, O = P V) this is the single-head d = 512, L = 4096
  * attention of the VAE mid block (ldm_diffusers.py:297), where GEMM tiles beat the flash kernel. */

@@ -81,6 +81,20 @@ class AttentionArgs(ctypes.Structure):
     ]
 
 
+class AttentionBwdArgs(ctypes.Structure):
+    _fields_ = [
+        ("dtype", c_int),
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p), ("dout", c_void_p),
+        ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
+        ("ldq", c_int), ("ldk", c_int), ("ldv", c_int), ("ldo", c_int), ("lddo", c_int),
+        ("lddq", c_int), ("lddk", c_int), ("lddv", c_int),
+        ("B", c_int), ("H", c_int), ("Lq", c_int), ("Lk", c_int), ("D", c_int),
+        ("scale", c_float),
+        ("workspace", c_void_p),
+        ("workspace_bytes", c_size_t),
+    ]
+
+
 # every symbol include/madm_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("madm_abi_version", c_int, []),
@@ -138,6 +152,8 @@ SYMBOLS = [
     ("madm_nchw_f32_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("madm_conv2d_wgrad", c_int, [ctypes.POINTER(Conv2dWgradArgs), c_void_p]),
     ("madm_pack_dgrad_weights", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    ("madm_attention_bwd_workspace_bytes", c_size_t, [ctypes.POINTER(AttentionBwdArgs)]),
+    ("madm_attention_bwd", c_int, [ctypes.POINTER(AttentionBwdArgs), c_void_p]),
     ("madm_zero_insert2x", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     ("madm_sumpool2x2", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("madm_silu_bwd", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -487,6 +487,32 @@ def attention(q, k, v, B, H, Lq, Lk, D, scale, out=None):
     return out
 
 
+def attention_backward(q, k, v, o, dout, B, H, Lq, Lk, D, scale):
+    """Backward of :func:`attention`: q / k / v / o / dout as in the forward (row-strided views with unit column
+    stride); returns dense (dq [B*Lq, H*D], dk [B*Lk, H*D], dv [B*Lk, H*D])."""
+    _need_cuda(q, k, v, o, dout)
+    for t in (q, k, v, o, dout):
+        assert t.stride(1) == 1 and t.dtype == q.dtype
+    dq = torch.empty((B * Lq, H * D), dtype=q.dtype, device=q.device)
+    dk = torch.empty((B * Lk, H * D), dtype=q.dtype, device=q.device)
+    dv = torch.empty((B * Lk, H * D), dtype=q.dtype, device=q.device)
+    a = _lib.AttentionBwdArgs()
+    a.dtype = dtype_code(q)
+    a.q, a.k, a.v, a.o, a.dout = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), dout.data_ptr()
+    a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), o.stride(0), dout.stride(0)
+    a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
+    a.B, a.H, a.Lq, a.Lk, a.D = B, H, Lq, Lk, D
+    a.scale = float(scale)
+    nbytes = lib.madm_attention_bwd_workspace_bytes(ctypes.byref(a))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    with _Prof(f"attn_bwd_d{D}" + ("_f32" if q.dtype == torch.float32 else "_bf16"), 14.0 * B * H * Lq * Lk * D,
+               f"B{B} H{H} Lq{Lq} Lk{Lk}"):
+        check(lib.madm_attention_bwd(ctypes.byref(a), _stream()), "madm_attention_bwd")
+    return dq, dk, dv
+
+
 def image_to_nhwc(img, dtype, Cpad, mean, std, minmax=None):
     _need_cuda(img, minmax)
     assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4

@@ -596,6 +596,39 @@ def test_attention(cuda, dtype, case):
     assert e < (2e-5 if dtype == torch.float32 else 1.5e-2), f"{e:.3e} {l2:.3e}"
 
 
+ATTN_BWD_CASES = [(2, 8, 64, 64, 40), (1, 8, 200, 200, 80), (2, 8, 64, 64, 160), (2, 8, 256, 77, 40),
+                  (1, 8, 100, 77, 80), (1, 2, 70, 130, 64), (1, 8, 1024, 1024, 80)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", ATTN_BWD_CASES, ids=[f"B{c[0]}H{c[1]}q{c[2]}k{c[3]}d{c[4]}" for c in ATTN_BWD_CASES])
+def test_attention_backward(cuda, dtype, case):
+    """madm_attention_bwd (recomputed log-sum-exp, dq pass + dk/dv pass) equals torch autograd through
+    F.scaled_dot_product_attention for self- and cross-attention shapes incl. ragged tails."""
+    from madm_amd import ops
+    B, H, Lq, Lk, D = case
+    q = _q(_gen((B, Lq, H, D), 1), dtype).requires_grad_(True)
+    k = _q(_gen((B, Lk, H, D), 2), dtype).requires_grad_(True)
+    v = _q(_gen((B, Lk, H, D), 3), dtype).requires_grad_(True)
+    scale = D ** -0.5
+    ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), scale=scale)
+    ref = ref.transpose(1, 2).reshape(B * Lq, H * D)
+    do = _q(_gen((B * Lq, H * D), 4), dtype)
+    ref.backward(do)
+    C = H * D
+    qd = q.detach().reshape(B * Lq, C).to(dtype).cuda()
+    kv = torch.cat([k.detach().reshape(B * Lk, C), v.detach().reshape(B * Lk, C)], 1).to(dtype).cuda()
+    kd, vd = kv[:, :C], kv[:, C:]
+    out = ops.attention(qd, kd, vd, B, H, Lq, Lk, D, scale)
+    dq, dk, dv = ops.attention_backward(qd, kd, vd, out, do.to(dtype).cuda(), B, H, Lq, Lk, D, scale)
+    torch.cuda.synchronize()
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    for name, got, want in (("dq", dq, q.grad), ("dk", dk, k.grad), ("dv", dv, v.grad)):
+        rows = B * (Lq if name == "dq" else Lk)
+        e, l2 = rel_err(got.float().cpu(), want.reshape(rows, C))
+        assert e < tol, f"{name}: {e:.3e} {l2:.3e}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_vae_attention_gemm_path_equals_flash_path(cuda, dtype):
     """The VAE mid-block attention as GEMMs (S = QK^T in f32, row softmax, P V with V^T from a swapped GEMM,
