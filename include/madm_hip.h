@@ -366,7 +366,8 @@ int madm_silu_bwd(int dtype, const void* x, const void* dy, void* dx, size_t n, 
  *              dgamma / dbeta (f32 [Ctot], accumulated into) are given, dgamma[c] += sum_b S2, dbeta[c] += sum_b S1;
  *              dres (NULL or [B*HW][lddres], read at column c_off + c) is added to dx: the gradient that reaches x
  *              through a skip path (ResnetBlock2D's shortcut).
- * madm_layernorm_bwd: dx [M][C] of madm_layernorm_fwd; dgamma / dbeta (f32 [C], accumulated into) may both be NULL.
+ * madm_layernorm_bwd: dx [M][C] of madm_layernorm_fwd (+ dres [M][C] or NULL: the gradient arriving through the
+ * block's residual connection); dgamma / dbeta (f32 [C], accumulated into) may both be NULL.
  * torch autograd in the reference (engine/train_loop.py:203-217) through diffusers' GroupNorm / LayerNorm modules
  * (ldm_diffusers.py:290,297,299-300,387,435,553,609-610). */
 int madm_groupnorm_bwd_sums(int dtype, const void* x, const void* dy, int lddy, int B, int HW, int C, int c_off, int Ctot,
@@ -377,7 +378,11 @@ int madm_groupnorm_bwd_apply(int dtype, const void* x, const void* dy, int lddy,
                              const float* beta, float eps, int act, const double* bsums, float* dgamma, float* dbeta,
                              const void* dres, int lddres, void* stream);
 int madm_layernorm_bwd(int dtype, const void* x, const void* dy, void* dx, int M, int C, const float* gamma, float eps,
-                       float* dgamma, float* dbeta, void* stream);
+                       float* dgamma, float* dbeta, const void* dres, void* stream);
+/* GEGLU backward (diffusers GEGLU inside BasicTransformerBlock.ff): pre [M][N2] are the dense pre-activation rows of
+ * the GEGLU GEMM in its interleaved (value_j, gate_j) order (madm_conv2d_fwd with MADM_EPI_NONE on the same packed
+ * weights), dout [M][N2 / 2] the gradient of value * gelu_erf(gate); dpre [M][N2] in the same interleaved order. */
+int madm_geglu_bwd(int dtype, const void* pre, const void* dout, void* dpre, size_t M, int N2, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Training-step tail on ONE flat, 16-byte-aligned fp32 buffer per role (HBM-bound).

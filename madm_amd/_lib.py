@@ -163,7 +163,8 @@ SYMBOLS = [
                                          c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     ("madm_layernorm_bwd", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p,
-                                   c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p]),
+    ("madm_geglu_bwd", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
 ]
 
 

@@ -216,7 +216,7 @@ template <typename T, int MAXCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                             T* __restrict__ dx, int M, int C,
                                                             const float* __restrict__ gamma, float eps, float* dgamma,
-                                                            float* dbeta) {
+                                                            float* dbeta, const T* __restrict__ dres) {
     constexpr int EPC = TT<T>::EPC;
     const int lane = threadIdx.x & 63;
     const int CPR = C / EPC;
@@ -291,9 +291,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int i = 0; i < MAXCH; ++i) {
             const int q = lane + 64 * i;
             if (q < CPR) {
-                float o[EPC];
+                float o[EPC], rf[EPC];
 #pragma unroll
-                for (int j = 0; j < EPC; ++j) o[j] = rstd * (gm[i][j] * d[i][j] - m1 - f[i][j] * m2);
+                for (int j = 0; j < EPC; ++j) rf[j] = 0.f;
+                if (dres) chunk_to_f32<T>(*reinterpret_cast<const uint4*>(dres + (size_t)row * C + q * EPC), rf);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) o[j] = rstd * (gm[i][j] * d[i][j] - m1 - f[i][j] * m2) + rf[j];
                 *reinterpret_cast<uint4*>(orow + q * EPC) = f32_to_chunk<T>(o);
             }
         }
@@ -310,6 +313,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 }
             }
         }
+    }
+}
+
+// GEGLU backward on the interleaved pre-activation rows (value_j, gate_j) the GEGLU GEMM accumulates (pack_geglu_weight
+// order): out_j = value_j * gelu(gate_j) ->  dvalue_j = dout_j * gelu(gate_j),  dgate_j = dout_j * value_j * gelu'(gate_j),
+// gelu'(g) = Phi(g) + g * phi(g) (exact-erf GELU).  One 16-byte chunk of pre (EPC / 2 pairs) + 8 bytes of dout per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* __restrict__ pre, const T* __restrict__ dout,
+                                                        T* __restrict__ dpre, size_t chunks) {
+    constexpr int EPC = TT<T>::EPC, HP = EPC / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
+        float pv[EPC], o[EPC], dv[HP];
+        chunk_to_f32<T>(*reinterpret_cast<const uint4*>(pre + i * EPC), pv);
+        const T* dp = dout + i * HP;
+#pragma unroll
+        for (int j = 0; j < HP; ++j) dv[j] = TT<T>::ld(dp + j);
+#pragma unroll
+        for (int j = 0; j < HP; ++j) {
+            const float val = pv[2 * j], g = pv[2 * j + 1];
+            const float cdf = 0.5f * (1.0f + erff(g * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * __expf(-0.5f * g * g);
+            o[2 * j] = dv[j] * g * cdf;
+            o[2 * j + 1] = dv[j] * val * (cdf + g * pdf);
+        }
+        *reinterpret_cast<uint4*>(dpre + i * EPC) = f32_to_chunk<T>(o);
     }
 }
 
@@ -377,8 +405,20 @@ int madm_groupnorm_bwd_apply(int dtype, const void* x, const void* dy, int lddy,
     return madm_check_launch("gn_bwd_apply_kernel");
 }
 
+int madm_geglu_bwd(int dtype, const void* pre, const void* dout, void* dpre, size_t M, int N2, void* stream) {
+    MADM_REQUIRE(pre && dout && dpre && M > 0 && N2 > 0, "geglu_bwd: bad argument");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(N2 % epc == 0, "geglu_bwd: 2N = %d must be a multiple of %d", N2, epc);
+    const size_t chunks = M * (size_t)(N2 / epc);
+    size_t blocks = (chunks + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    MADM_DISPATCH_DTYPE(dtype, (geglu_bwd_kernel<T><<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(
+                                   (const T*)pre, (const T*)dout, (T*)dpre, chunks)));
+    return madm_check_launch("geglu_bwd_kernel");
+}
+
 int madm_layernorm_bwd(int dtype, const void* x, const void* dy, void* dx, int M, int C, const float* gamma, float eps,
-                       float* dgamma, float* dbeta, void* stream) {
+                       float* dgamma, float* dbeta, const void* dres, void* stream) {
     MADM_REQUIRE(x && dy && dx && gamma && M > 0 && C > 0, "layernorm_bwd: bad argument");
     MADM_REQUIRE(!dgamma == !dbeta, "layernorm_bwd: dgamma and dbeta go together");
     const int epc = dtype == MADM_BF16 ? 8 : 4;
@@ -389,10 +429,10 @@ int madm_layernorm_bwd(int dtype, const void* x, const void* dy, void* dx, int M
     hipStream_t s = (hipStream_t)stream;
     if (C / epc <= 64 * 3)   // the UNet's widths in bf16 (320 / 640 / 1280): 3 chunks per lane keep the row state small
         MADM_DISPATCH_DTYPE(dtype, (layernorm_bwd_kernel<T, 3><<<dim3((unsigned)blocks), 256, 0, s>>>(
-                                       (const T*)x, (const T*)dy, (T*)dx, M, C, gamma, eps, dgamma, dbeta)));
+                                       (const T*)x, (const T*)dy, (T*)dx, M, C, gamma, eps, dgamma, dbeta, (const T*)dres)));
     else
         MADM_DISPATCH_DTYPE(dtype, (layernorm_bwd_kernel<T, 5><<<dim3((unsigned)blocks), 256, 0, s>>>(
-                                       (const T*)x, (const T*)dy, (T*)dx, M, C, gamma, eps, dgamma, dbeta)));
+                                       (const T*)x, (const T*)dy, (T*)dx, M, C, gamma, eps, dgamma, dbeta, (const T*)dres)));
     return madm_check_launch("layernorm_bwd_kernel");
 }
 

@@ -441,19 +441,31 @@ def groupnorm_backward(xs, dy, B, HW, G, gamma, beta, eps, stats, act=None, dgam
     return dxs, dgamma, dbeta
 
 
-def layernorm_backward(x, dy, gamma, eps, dgamma=None, dbeta=None):
+def layernorm_backward(x, dy, gamma, eps, dgamma=None, dbeta=None, dres=None):
     """Backward of :func:`layernorm`: returns (dx, dgamma, dbeta); dgamma / dbeta f32 [C] are accumulated into when
-    given, created zeroed otherwise."""
-    _need_cuda(x, dy, gamma, dgamma, dbeta)
+    given, created zeroed otherwise; ``dres`` (dense, like x) is added to dx."""
+    _need_cuda(x, dy, gamma, dgamma, dbeta, dres)
+    assert dres is None or (dres.is_contiguous() and dres.shape == x.shape and dres.dtype == x.dtype)
     assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape and x.dtype == dy.dtype and x.dim() == 2
     if dgamma is None:
         dgamma = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
         dbeta = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     check(lib.madm_layernorm_bwd(dtype_code(x), x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.shape[0], x.shape[1],
-                                 gamma.data_ptr(), float(eps), dgamma.data_ptr(), dbeta.data_ptr(), _stream()),
+                                 gamma.data_ptr(), float(eps), dgamma.data_ptr(), dbeta.data_ptr(), _ptr(dres), _stream()),
           "madm_layernorm_bwd")
     return dx, dgamma, dbeta
+
+
+def geglu_backward(pre, dout):
+    """pre [M, 2N] interleaved (value, gate) pre-activations, dout [M, N] -> dpre [M, 2N] (same order)."""
+    _need_cuda(pre, dout)
+    assert pre.is_contiguous() and dout.is_contiguous() and pre.dtype == dout.dtype
+    assert pre.shape[0] == dout.shape[0] and pre.shape[1] == 2 * dout.shape[1]
+    dpre = torch.empty_like(pre)
+    check(lib.madm_geglu_bwd(dtype_code(pre), pre.data_ptr(), dout.data_ptr(), dpre.data_ptr(), pre.shape[0],
+                             pre.shape[1], _stream()), "madm_geglu_bwd")
+    return dpre
 
 
 def layernorm(x, gamma, beta, eps, out=None):
@@ -487,15 +499,21 @@ def attention(q, k, v, B, H, Lq, Lk, D, scale, out=None):
     return out
 
 
-def attention_backward(q, k, v, o, dout, B, H, Lq, Lk, D, scale):
+def attention_backward(q, k, v, o, dout, B, H, Lq, Lk, D, scale, outs=None):
     """Backward of :func:`attention`: q / k / v / o / dout as in the forward (row-strided views with unit column
-    stride); returns dense (dq [B*Lq, H*D], dk [B*Lk, H*D], dv [B*Lk, H*D])."""
+    stride); returns (dq [B*Lq, H*D], dk [B*Lk, H*D], dv [B*Lk, H*D]) -- dense, or the row-strided views given
+    as ``outs`` (e.g. the three column windows of one [M, 3C] buffer for the fused QKV projection's backward)."""
     _need_cuda(q, k, v, o, dout)
     for t in (q, k, v, o, dout):
         assert t.stride(1) == 1 and t.dtype == q.dtype
-    dq = torch.empty((B * Lq, H * D), dtype=q.dtype, device=q.device)
-    dk = torch.empty((B * Lk, H * D), dtype=q.dtype, device=q.device)
-    dv = torch.empty((B * Lk, H * D), dtype=q.dtype, device=q.device)
+    if outs is not None:
+        dq, dk, dv = outs
+        for t, rows in ((dq, B * Lq), (dk, B * Lk), (dv, B * Lk)):
+            assert t.is_cuda and t.stride(1) == 1 and t.dtype == q.dtype and tuple(t.shape) == (rows, H * D)
+    else:
+        dq = torch.empty((B * Lq, H * D), dtype=q.dtype, device=q.device)
+        dk = torch.empty((B * Lk, H * D), dtype=q.dtype, device=q.device)
+        dv = torch.empty((B * Lk, H * D), dtype=q.dtype, device=q.device)
     a = _lib.AttentionBwdArgs()
     a.dtype = dtype_code(q)
     a.q, a.k, a.v, a.o, a.dout = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), dout.data_ptr()
