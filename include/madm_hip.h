@@ -325,7 +325,7 @@ int madm_argmax_nchw_f32(const float* x, int64_t* out, int B, int K, size_t HW, 
  * is ACCUMULATED into (gradient accumulation; zero it for a plain gradient); the pixel range is split over `splitm`
  * grid slices (0 = choose) that add their partial tiles with float atomics, so the low-order bits depend on
  * scheduling, like torch's own non-deterministic wgrad algorithms.
- * bias gradient = column sums of dout: madm_groupnorm_stats(dout) gives them per image.
+ * bias gradient = column sums of dout: madm_colsum.
  *
  * Data gradient of a stride-1 layer (3x3 / pad 1, 1x1, linear): din = madm_conv2d_fwd(dout, wt) with
  * pad' = KH - 1 - pad and wt[c][taps - 1 - t][n] = w[n][t][c], produced by madm_pack_dgrad_weights
@@ -355,6 +355,12 @@ int madm_pack_dgrad_weights(int dtype, const void* w, void* wt, int N, int taps,
 int madm_zero_insert2x(int dtype, const void* x, void* y, int B, int OH, int OW, int H, int W, int C, void* stream);
 int madm_sumpool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream);
 int madm_silu_bwd(int dtype, const void* x, const void* dy, void* dx, size_t n, void* stream);
+/* y = a + b over n elements of dtype (n a multiple of 16 bytes): gradient accumulation where one tensor feeds two
+ * consumers (UNet skip connections, the feature taps of ldm_diffusers.py:442-445). */
+int madm_add(int dtype, const void* a, const void* b, void* y, size_t n, void* stream);
+/* out[b][c] (f32 [B][C], accumulated into) += sum over the HW rows of image b of x[b*HW + r][c] (row stride ldx): the
+ * bias gradient (B = 1 over all rows) and ResnetBlock2D's per-image time-row gradient. */
+int madm_colsum(int dtype, const void* x, int ldx, int B, int HW, int C, float* out, void* stream);
 
 /* Backward of madm_groupnorm_apply (without its residual input, whose gradient is dz itself) in two passes over
  * the source x [B*HW][C] occupying channels [c_off, c_off + C) of the Ctot-channel (possibly two-source) tensor; dy

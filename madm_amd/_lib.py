@@ -157,6 +157,8 @@ SYMBOLS = [
     ("madm_zero_insert2x", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     ("madm_sumpool2x2", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("madm_silu_bwd", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("madm_add", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("madm_colsum", c_int, [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("madm_groupnorm_bwd_sums", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     ("madm_groupnorm_bwd_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -18,11 +18,8 @@ from .nn import Tok
 
 
 def _colsum_per_image(t, B, HW):
-    """f32 [B, C] per-image column sums of a [B*HW, C] gradient (bias / time-row gradients): the channel-sum kernel of
-    the GroupNorm statistics."""
-    sums = ops.new_chsums(B, t.shape[1], t.device)
-    ops.groupnorm_stats(t, B, HW, sums)
-    return sums[:, :, 0].float()
+    """f32 [B, C] per-image column sums of a [B*HW, C] gradient (bias / time-row gradients)."""
+    return ops.colsum(t, B, HW)
 
 
 def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None, upsample=False):
@@ -36,6 +33,8 @@ def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None, upsample=Fa
     pad = 0 if conv.asym_pad else conv.padding
     OH, OW = conv.out_hw(x.H, x.W, upsample)
     splits = None if x2 is None else [x.C, x2.C]
+    if dout.shape[1] % kt:   # conv_out (4 channels): the data gradient is a forward conv over dout's channels, whose
+        dout = torch.nn.functional.pad(dout, (0, packing.round_up(dout.shape[1], kt) - dout.shape[1]))   # count fills a K-tile
     dwp = ops.conv2d_wgrad(x.t, dout, x.B, x.H, x.W, x2=None if x2 is None else x2.t, KH=k, KW=k, stride=conv.stride,
                            pad_t=pad, pad_l=pad, OH=OH, OW=OW, upsample=upsample)
     dw = packing.unpack_conv_weight_grad(dwp[:conv.out_channels], conv.in_channels, k, k, kt, splits=splits)
@@ -45,6 +44,8 @@ def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None, upsample=Fa
     dx = None
     if need_dx:
         wp, _ = conv.packed(dtype, splits)
+        if wp.shape[0] != dout.shape[1]:   # conv_out: dout was widened to a K-tile above
+            wp = torch.nn.functional.pad(wp, (0, 0, 0, dout.shape[1] - wp.shape[0]))
         wt = ops.pack_dgrad_weights(wp, k * k)
         if conv.stride == 1 and not upsample:
             dx = ops.conv2d_dgrad(dout, wt, x.B, x.H, x.W, C=wt.shape[0], KH=k, KW=k, pad_t=pad, pad_l=pad, residual=dres)
@@ -293,3 +294,263 @@ def transformer_block_backward(blk, h, dout, B, L, ctx, Lk, kv=None, base_grads=
 def _cols(t, C):
     """dense [M, C] from a data gradient whose row was padded to the K-tile."""
     return t if t.shape[1] == C else t[:, :C].contiguous()
+
+
+# ----------------------------------------------------------------------------- whole UNet
+def _ensure_stats(tok):
+    if tok.stats is None:
+        tok.stats = ops.new_chsums(tok.B, tok.C, tok.t.device)
+        ops.groupnorm_stats(tok.t, tok.B, tok.HW, tok.stats)
+    return tok.stats
+
+
+def transformer2d_backward(tr, x, dout, ctx, Lk, kvs=None, base_grads=True):
+    """Backward of ``sd_unet.Transformer2DModel.forward(x, ctx, Lk)`` = proj_out(blocks(proj_in(GroupNorm(x)))) + x:
+    returns (dx [M, C], [dctx or dkv per block], grads).  ``kvs``: {id(attn2): precomputed K/V view} or None."""
+    B, L = x.B, x.HW
+    _ensure_stats(x)
+    n = tr.norm(x)
+    hin = tr.proj_in(n, stats=False)
+    t_in, t = [], hin.t
+    for blk in tr.transformer_blocks:
+        t_in.append(t)
+        kv = None if kvs is None else kvs.get(id(blk.attn2))
+        t = blk(t, B, L, ctx, Lk) if kv is None else _block_forward_kv(blk, t, B, L, Lk, kv)
+    grads = {}
+    dt, g = conv2d_backward(tr.proj_out, x.like(t), dout)
+    grads.update({"proj_out." + k_: v for k_, v in g.items()} if base_grads else {})
+    C = t.shape[1]
+    dkvs = []
+    for i in reversed(range(len(tr.transformer_blocks))):
+        blk = tr.transformer_blocks[i]
+        kv = None if kvs is None else kvs.get(id(blk.attn2))
+        dt, dkv, g = transformer_block_backward(blk, t_in[i], _cols(dt, C), B, L, ctx, Lk, kv=kv, base_grads=base_grads)
+        grads.update({f"transformer_blocks.{i}." + k_: v for k_, v in g.items()})
+        dkvs.insert(0, dkv)
+    dn, g = conv2d_backward(tr.proj_in, n, _cols(dt, C))
+    grads.update({"proj_in." + k_: v for k_, v in g.items()} if base_grads else {})
+    (dx,), dg, db = ops.groupnorm_backward([x.t], dn, B, L, tr.norm.num_groups, tr.norm.weight.detach().float(),
+                                           tr.norm.bias.detach().float(), tr.norm.eps, [x.stats], act="none", dres=dout)
+    grads["norm.weight"], grads["norm.bias"] = dg, db
+    return dx, dkvs, grads
+
+
+def _block_forward_kv(blk, h, B, L, Lk, kv):
+    from .sd_unet import CtxKV
+    return blk(h, B, L, CtxKV(None, {id(blk.attn2): kv}), Lk)
+
+
+class _Tape:
+    """Gradients keyed by the activation tensors of a recorded forward (the tape keeps them alive, so data_ptr() is a
+    unique key); a tensor feeding several consumers accumulates through madm_add."""
+
+    def __init__(self):
+        self.records = []
+        self.g = {}
+
+    def add(self, t, g):
+        cur = self.g.get(t.data_ptr())
+        self.g[t.data_ptr()] = g if cur is None else ops.add(cur, g.contiguous())
+
+    def pop(self, t):
+        return self.g.pop(t.data_ptr(), None)
+
+
+def unet_backward(unet, sample, timesteps, ctx, Lk, dtaps, unet_block_indices, cond_emb=None, dsample=None,
+                  base_grads=True):
+    """Backward of ``sd_unet.UNet2DConditionModel.forward(sample, timesteps, ctx, Lk, cond_emb, unet_block_indices,
+    'after')`` for the gradients ``dtaps`` of the tapped features ([M_i, C_i] tensors, same order) and, optionally,
+    ``dsample`` of the final sample ([M, n_pad]).  The forward is re-run here block by block (only block INPUTS are
+    kept; each block's backward recomputes its interior), then walked in reverse.
+
+    Returns {"sample": d latents [M, Cpad], "ctx": d prompt tokens [B*Lk, 768], "cond_emb": f32 [B, 1280] or None,
+    "grads": {parameter name: f32 gradient}} -- with ``base_grads=False`` (the reference's LoRA mode) only LoRA A / B,
+    the norms' affine parameters and the time-row projections come back."""
+    from .sd_unet import CtxKV
+    dtype = sample.t.dtype
+    B = sample.B
+    names = {id(m): n for n, m in unet.named_modules()}
+    tape = _Tape()
+    rec = tape.records
+
+    # ---- recorded forward (mirrors UNet2DConditionModel.forward) ----
+    freqs = ops.timestep_freqs(unet.block_out_channels[0], sample.t.device)
+    t_emb = ops.timestep_embedding(timesteps, freqs, dtype)
+    te = unet.time_embedding
+    e1 = te.linear_1(t_emb)
+    a1 = ops.silu(e1)
+    res = None if cond_emb is None else ops.cast_from_f32(cond_emb.contiguous(), dtype)
+    emb = te.linear_2(a1, residual=res)
+    rows = unet._time_rows(emb)
+    ctxkv = unet._ctx_kv(ctx)
+    kvs = ctxkv.kv if isinstance(ctxkv, CtxKV) else None
+
+    def run_tr(tr, h):
+        out = tr(h, ctxkv, Lk)
+        rec.append(("tr", tr, h, out))
+        return out
+
+    def run_res(r, h, skip=None):
+        out = r(h, rows[id(r)], skip=skip)
+        rec.append(("res", r, h, skip, out))
+        return out
+
+    h = unet.conv_in(sample)
+    rec.append(("conv_in", unet.conv_in, sample, h))
+    skips = [h]
+    for blk in unet.down_blocks:
+        for i, r in enumerate(blk.resnets):
+            h = run_res(r, h)
+            if blk.has_cross_attention:
+                h = run_tr(blk.attentions[i], h)
+            skips.append(h)
+        if blk.downsamplers is not None:
+            for d in blk.downsamplers:
+                x_in = h
+                h = d(h)
+                rec.append(("conv", d.conv, x_in, h, False))
+            skips.append(h)
+    mb = unet.mid_block
+    h = run_res(mb.resnets[0], h)
+    for attn, r in zip(mb.attentions, mb.resnets[1:]):
+        h = run_tr(attn, h)
+        h = run_res(r, h)
+    idx, tapped = 0, []
+    for blk in unet.up_blocks:
+        for i, r in enumerate(blk.resnets):
+            h = run_res(r, h, skip=skips.pop())
+            if blk.has_cross_attention:
+                h = run_tr(blk.attentions[i], h)
+            if idx in unet_block_indices:
+                tapped.append(h)
+            idx += 1
+        if blk.upsamplers is not None:
+            for u in blk.upsamplers:
+                x_in = h
+                h = u(h)
+                rec.append(("conv", u.conv, x_in, h, True))
+    assert len(tapped) == len(dtaps)
+    for tk, g in zip(tapped, dtaps):
+        tape.add(tk.t, g)
+
+    grads = {}
+    dctx = None
+    drow = {}
+    dkv_of = {}
+
+    def put(prefix, g):
+        for k_, v in g.items():
+            grads[prefix + "." + k_] = v
+
+    # ---- conv_out(silu(conv_norm_out(h))) ----
+    if dsample is not None:
+        _ensure_stats(h)
+        a = unet.conv_norm_out(h, silu=True)
+        da, g = conv2d_backward(unet.conv_out, a, dsample)
+        if base_grads:
+            put("conv_out", g)
+        no = unet.conv_norm_out
+        (dh,), dg, db = ops.groupnorm_backward([h.t], da, B, h.HW, no.num_groups, no.weight.detach().float(),
+                                               no.bias.detach().float(), no.eps, [h.stats], act="silu")
+        grads["conv_norm_out.weight"], grads["conv_norm_out.bias"] = dg, db
+        tape.add(h.t, dh)
+
+    # ---- reverse walk ----
+    for r_ in reversed(rec):
+        kind = r_[0]
+        if kind == "res":
+            _, mod, x, skip, out = r_
+            dout = tape.pop(out.t)
+            if dout is None:
+                continue
+            dx, dskip, dtr, g = resnet_block_backward(mod, x, dout, temb_row=rows[id(mod)], skip=skip)
+            if not base_grads:
+                g = {k_: v for k_, v in g.items() if k_.startswith("norm")}
+            put(names[id(mod)], g)
+            drow[id(mod)] = dtr
+            tape.add(x.t, dx.t)
+            if skip is not None:
+                tape.add(skip.t, dskip.t)
+        elif kind == "tr":
+            _, mod, x, out = r_
+            dout = tape.pop(out.t)
+            if dout is None:
+                continue
+            dx, dkvs, g = transformer2d_backward(mod, x, dout, ctx, Lk, kvs=kvs, base_grads=base_grads)
+            put(names[id(mod)], g)
+            tape.add(x.t, dx)
+            for blk, dkv in zip(mod.transformer_blocks, dkvs):
+                if kvs is not None:
+                    dkv_of[id(blk.attn2)] = dkv
+                else:
+                    dctx = dkv if dctx is None else ops.add(dctx, dkv)
+        elif kind == "conv":
+            _, conv, x, out, ups = r_
+            dout = tape.pop(out.t)
+            if dout is None:
+                continue
+            dx, g = conv2d_backward(conv, x, dout, upsample=ups)
+            if base_grads:
+                put(names[id(conv)], g)
+            tape.add(x.t, dx)
+        elif kind == "conv_in":
+            _, conv, x, out = r_
+            dout = tape.pop(out.t)
+            dx, g = conv2d_backward(conv, x, dout)
+            if base_grads:
+                put("conv_in", g)
+            tape.add(x.t, dx)
+    dsample_in = tape.pop(sample.t)
+
+    # ---- batched K/V projection of the cross-attention layers (no LoRA on to_k / to_v) ----
+    if kvs is not None:
+        attns = unet._cross_attentions()
+        Wall = unet.__dict__["_ctxkv_cache"][dtype][1]
+        dall = torch.zeros((ctx.shape[0], Wall.shape[0]), dtype=dtype, device=ctx.device)
+        off = 0
+        for a_ in attns:
+            n = 2 * a_.heads * a_.dim_head
+            if id(a_) in dkv_of:
+                dall[:, off:off + n] = dkv_of[id(a_)]
+            off += n
+        dctx = ops.conv2d_dgrad(dall, ops.pack_dgrad_weights(Wall, 1), 1, ctx.shape[0], 1, C=Wall.shape[1])
+        if base_grads:
+            dW = ops.conv2d_wgrad(ctx, dall, 1, ctx.shape[0], 1)
+            off = 0
+            for a_ in attns:
+                c = a_.heads * a_.dim_head
+                grads[names[id(a_)] + ".to_k.weight"] = dW[off:off + c, :a_.to_k.in_features].contiguous()
+                grads[names[id(a_)] + ".to_v.weight"] = dW[off + c:off + 2 * c, :a_.to_v.in_features].contiguous()
+                off += 2 * c
+
+    # ---- time rows -> time embedding MLP ----
+    resnets = unet._resnets()
+    _, Wp, _ = unet.__dict__["_temb_cache"][dtype]
+    drows = torch.zeros((B, Wp.shape[0]), dtype=torch.float32, device=sample.t.device)
+    off = 0
+    for r in resnets:
+        n = r.time_emb_proj.out_features
+        if drow.get(id(r)) is not None:
+            drows[:, off:off + n] = drow[id(r)]
+        off += n
+    drows_c = ops.cast_from_f32(drows, dtype)
+    s_emb = ops.silu(emb)
+    dWs = ops.conv2d_wgrad(s_emb, drows_c, 1, B, 1)
+    dbs = drows.sum(0)
+    off = 0
+    for r in resnets:
+        n = r.time_emb_proj.out_features
+        grads[names[id(r)] + ".time_emb_proj.weight"] = dWs[off:off + n, :r.time_emb_proj.in_features].contiguous()
+        grads[names[id(r)] + ".time_emb_proj.bias"] = dbs[off:off + n].contiguous()
+        off += n
+    ds = ops.conv2d_dgrad(drows_c, ops.pack_dgrad_weights(Wp, 1), 1, B, 1, C=Wp.shape[1])
+    demb = ops.silu_backward(emb, _cols(ds, emb.shape[1]))
+    da1, g = linear_backward(te.linear_2, a1, demb)
+    if base_grads:
+        put("time_embedding.linear_2", g)
+    de1 = ops.silu_backward(e1, _cols(da1, e1.shape[1]))
+    _, g = linear_backward(te.linear_1, t_emb, de1, need_dx=False)
+    if base_grads:
+        put("time_embedding.linear_1", g)
+    return {"sample": dsample_in, "ctx": dctx, "cond_emb": ops.rows_to_f32(demb) if cond_emb is not None else None,
+            "grads": grads}

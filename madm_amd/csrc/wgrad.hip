@@ -295,6 +295,46 @@ __global__ void silu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ d
     }
 }
 
+// y = a + b (gradient accumulation where a tensor feeds two consumers: UNet skip connections, feature taps)
+template <typename T>
+__global__ void add_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ y, size_t chunks) {
+    constexpr int EPC = TT<T>::EPC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
+        float fa[EPC], fb[EPC];
+        chunk_to_f32<T>(a[i], fa);
+        chunk_to_f32<T>(b[i], fb);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) fa[j] += fb[j];
+        y[i] = f32_to_chunk<T>(fa);
+    }
+}
+
+// out[b][c] += sum over the HW rows of image b of x[b * HW + r][c]: bias / time-row gradients.  grid (column chunks / 256,
+// row slices, B); a thread owns one 16-byte column chunk, sums its slice in f32 and adds it with float atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ldx, int HW, int C, int rows_per_slice,
+                                                     float* __restrict__ out) {
+    constexpr int EPC = TT<T>::EPC;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q * EPC >= C) return;
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * rows_per_slice;
+    int r1 = r0 + rows_per_slice;
+    if (r1 > HW) r1 = HW;
+    float s[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) s[j] = 0.f;
+    const T* xb = x + ((size_t)b * HW) * ldx + q * EPC;
+    for (int r = r0; r < r1; ++r) {
+        float f[EPC];
+        chunk_to_f32<T>(*reinterpret_cast<const uint4*>(xb + (size_t)r * ldx), f);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) s[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) unsafeAtomicAdd(out + (size_t)b * C + q * EPC + j, s[j]);
+}
+
 unsigned bwd_grid_for(size_t n) {
     size_t b = (n + 255) / 256;
     return (unsigned)(b > 16384 ? 16384 : (b ? b : 1));
@@ -322,6 +362,31 @@ extern "C" int madm_sumpool2x2(int dtype, const void* x, void* y, int B, int H, 
     MADM_DISPATCH_DTYPE(dtype, (sumpool2x2_kernel<T><<<bwd_grid_for(total), 256, 0, (hipStream_t)stream>>>(
                                    (const T*)x, (T*)y, H, W, C, total)));
     return madm_check_launch("sumpool2x2_kernel");
+}
+
+extern "C" int madm_colsum(int dtype, const void* x, int ldx, int B, int HW, int C, float* out, void* stream) {
+    MADM_REQUIRE(x && out && B > 0 && HW > 0 && C > 0, "colsum: bad argument");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(C % epc == 0 && ldx % epc == 0 && ldx >= C, "colsum: C / ldx must be multiples of %d elements", epc);
+    int slices = (HW + 255) / 256;
+    if (slices > 1024) slices = 1024;
+    const int rows_per_slice = (HW + slices - 1) / slices;
+    slices = (HW + rows_per_slice - 1) / rows_per_slice;
+    MADM_REQUIRE(B <= 65535, "colsum: too many images");
+    dim3 grid((unsigned)((C / epc + 255) / 256), (unsigned)slices, (unsigned)B);
+    MADM_DISPATCH_DTYPE(dtype, (colsum_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T*)x, ldx, HW, C,
+                                                                                        rows_per_slice, out)));
+    return madm_check_launch("colsum_kernel");
+}
+
+extern "C" int madm_add(int dtype, const void* a, const void* b, void* y, size_t n, void* stream) {
+    MADM_REQUIRE(a && b && y && n > 0, "add: bad argument");
+    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    MADM_REQUIRE(n % epc == 0, "add: n must be a multiple of %d elements", epc);
+    const size_t chunks = n / epc;
+    MADM_DISPATCH_DTYPE(dtype, (add_kernel<T><<<bwd_grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
+                                   (const uint4*)a, (const uint4*)b, (uint4*)y, chunks)));
+    return madm_check_launch("add_kernel");
 }
 
 extern "C" int madm_silu_bwd(int dtype, const void* x, const void* dy, void* dx, size_t n, void* stream) {

@@ -295,6 +295,27 @@ def sumpool2x2(x, B, H, W):
     return y
 
 
+def colsum(x, B, HW, out=None):
+    """f32 [B, C] per-image column sums of x [B*HW, C] (row-strided view allowed); accumulated into ``out`` if given."""
+    _need_cuda(x, out)
+    assert x.stride(1) == 1 and x.shape[0] == B * HW
+    if out is None:
+        out = torch.zeros((B, x.shape[1]), dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (B, x.shape[1])
+    check(lib.madm_colsum(dtype_code(x), x.data_ptr(), x.stride(0), B, HW, x.shape[1], out.data_ptr(), _stream()),
+          "madm_colsum")
+    return out
+
+
+def add(a, b):
+    """a + b for two dense tensors of the compute dtype (gradient accumulation)."""
+    _need_cuda(a, b)
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == b.dtype
+    y = torch.empty_like(a)
+    check(lib.madm_add(dtype_code(a), a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _stream()), "madm_add")
+    return y
+
+
 def silu_backward(x, dy):
     _need_cuda(x, dy)
     assert x.is_contiguous() and dy.is_contiguous() and x.shape == dy.shape and x.dtype == dy.dtype
