@@ -224,7 +224,7 @@ def test_unet_backward_equals_oracle_autograd(cuda, dtype, lora):
     kernels, interiors recomputed) against torch autograd through the CPU oracle's diffusion_unet for a loss that is
     linear in the three tapped features and the final sample: gradients of the latents, the prompt tokens, the
     time-embedding residual and EVERY parameter (peft-style LoRA active on q / k / v / out in the 'lora' case).
-    Tolerances as for the forward goldens: f32 mode 2e-3 of the tensor's max magnitude; bf16 mode relative L2 against
+    Tolerances as for the forward goldens: f32 mode 1e-3 of the tensor's max magnitude; bf16 mode relative L2 against
     the SAME f32 reference (bf16 storage of weights and activations through ~120 layers forward + backward)."""
     from madm_amd import backward, ops
     from madm_amd.nn import Tok
@@ -238,7 +238,7 @@ def test_unet_backward_equals_oracle_autograd(cuda, dtype, lora):
                                  r["taps"], cond_emb=r["cond"].detach().cuda(), dsample=to_tokens(r["gout"], dtype))
     torch.cuda.synchronize()
     want = r["want"]
-    BF16_GRAD_L2 = 0.15
+    BF16_GRAD_L2 = 8e-2   # observed worst over the 945 tensors: 4.5e-2 (f32 mode: 6.5e-6 max-relative)
 
     def check(name, got, ref_t):
         # the mid block runs on a 1x1 map here: self-attention over ONE key has softmax == 1, so dq = dk = 0 and the
@@ -248,7 +248,7 @@ def test_unet_backward_equals_oracle_autograd(cuda, dtype, lora):
             worst = max(float(got.abs().max()), float(ref_t.abs().max())) / scale
             return worst < (1e-3 if dtype == torch.float32 else 5e-2), f"{name}: zero-gradient layer, {worst:.2e} of to_v l2 0"
         e, l2 = rel_err(got, ref_t)
-        ok = (e < 2e-3) if dtype == torch.float32 else (l2 < BF16_GRAD_L2)
+        ok = (e < F32_TOL) if dtype == torch.float32 else (l2 < BF16_GRAD_L2)
         return ok, f"{name}: max {e:.2e} l2 {l2:.2e}"
 
     results = [check("d sample", from_tokens(res["sample"], B, hw, hw)[:, :4], r["sample"].grad),
