@@ -22,7 +22,7 @@ def _colsum_per_image(t, B, HW):
     return ops.colsum(t, B, HW)
 
 
-def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None, upsample=False):
+def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None, upsample=False, need_dw=True):
     """Gradients of ``conv(x, x2, upsample=...)`` (plain conv: the caller handles a fused norm) for the ``nn.Conv2d``
     twin ``conv``: returns (dx_cat [M_in, C1(+C2)] or None, {"weight": ..., "bias": ...}).  ``dres`` (stride-1 layers)
     is added to dx.  Stride-2 layers (Downsample2D, both paddings) run the stride-1 data gradient on the zero-inserted
@@ -35,18 +35,25 @@ def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None, upsample=Fa
     splits = None if x2 is None else [x.C, x2.C]
     if dout.shape[1] % kt:   # conv_out (4 channels): the data gradient is a forward conv over dout's channels, whose
         dout = torch.nn.functional.pad(dout, (0, packing.round_up(dout.shape[1], kt) - dout.shape[1]))   # count fills a K-tile
-    dwp = ops.conv2d_wgrad(x.t, dout, x.B, x.H, x.W, x2=None if x2 is None else x2.t, KH=k, KW=k, stride=conv.stride,
-                           pad_t=pad, pad_l=pad, OH=OH, OW=OW, upsample=upsample)
-    dw = packing.unpack_conv_weight_grad(dwp[:conv.out_channels], conv.in_channels, k, k, kt, splits=splits)
-    grads = {"weight": dw}
-    if conv.bias is not None:
-        grads["bias"] = _colsum_per_image(dout, x.B, OH * OW).sum(0)[:conv.out_channels]
+    grads = {}
+    if need_dw:   # False: frozen layer (the reference's LoRA mode), only the data gradient flows
+        dwp = ops.conv2d_wgrad(x.t, dout, x.B, x.H, x.W, x2=None if x2 is None else x2.t, KH=k, KW=k,
+                               stride=conv.stride, pad_t=pad, pad_l=pad, OH=OH, OW=OW, upsample=upsample)
+        grads["weight"] = packing.unpack_conv_weight_grad(dwp[:conv.out_channels], conv.in_channels, k, k, kt,
+                                                          splits=splits)
+        if conv.bias is not None:
+            grads["bias"] = _colsum_per_image(dout, x.B, OH * OW).sum(0)[:conv.out_channels]
     dx = None
     if need_dx:
-        wp, _ = conv.packed(dtype, splits)
-        if wp.shape[0] != dout.shape[1]:   # conv_out: dout was widened to a K-tile above
-            wp = torch.nn.functional.pad(wp, (0, 0, 0, dout.shape[1] - wp.shape[0]))
-        wt = ops.pack_dgrad_weights(wp, k * k)
+        def build_wt():
+            wp, _ = conv.packed(dtype, splits)
+            if wp.shape[0] != dout.shape[1]:   # conv_out: dout was widened to a K-tile above
+                wp = torch.nn.functional.pad(wp, (0, 0, 0, dout.shape[1] - wp.shape[0]))
+            return ops.pack_dgrad_weights(wp, k * k)
+
+        # transposed / tap-reversed weights live in the module's packed-operand cache (re-derived when a parameter's
+        # version moves, like the forward operands)
+        wt = conv._cache_get((dtype, tuple(splits) if splits else None, "dgrad"), build_wt)
         if conv.stride == 1 and not upsample:
             dx = ops.conv2d_dgrad(dout, wt, x.B, x.H, x.W, C=wt.shape[0], KH=k, KW=k, pad_t=pad, pad_l=pad, residual=dres)
         elif conv.stride == 2 and not upsample:
@@ -62,22 +69,24 @@ def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None, upsample=Fa
     return dx, grads
 
 
-def linear_backward(lin, x, dout, need_dx=True):
+def linear_backward(lin, x, dout, need_dx=True, need_dw=True):
     """Gradients of ``lin(x)``: (dx [M, K] or None, {"weight", "bias"})."""
     dtype = x.dtype
     M = x.shape[0]
-    dwp = ops.conv2d_wgrad(x, dout, 1, M, 1)
-    grads = {"weight": dwp[:, :lin.in_features].contiguous()}
-    if lin.bias is not None:
-        grads["bias"] = _colsum_per_image(dout, 1, M)[0]
+    grads = {}
+    if need_dw:
+        dwp = ops.conv2d_wgrad(x, dout, 1, M, 1)
+        grads["weight"] = dwp[:, :lin.in_features].contiguous()
+        if lin.bias is not None:
+            grads["bias"] = _colsum_per_image(dout, 1, M)[0]
     dx = None
     if need_dx:
-        wp, _ = lin.packed(dtype)
-        dx = ops.conv2d_dgrad(dout, ops.pack_dgrad_weights(wp, 1), 1, M, 1, C=wp.shape[1])
+        wt = lin._cache_get((dtype, "dgrad"), lambda: ops.pack_dgrad_weights(lin.packed(dtype)[0], 1))
+        dx = ops.conv2d_dgrad(dout, wt, 1, M, 1, C=wt.shape[0])
     return dx, grads
 
 
-def resnet_block_backward(block, x, dout, temb_row=None, skip=None):
+def resnet_block_backward(block, x, dout, temb_row=None, skip=None, base_grads=True):
     """Backward of ``sd_unet.ResnetBlock2D.forward(x, temb_row, skip)`` for the output gradient ``dout`` [M, Cout]:
 
         h   = conv1(silu(norm1([x | skip]))) + b1 + temb_row[image]
@@ -102,7 +111,7 @@ def resnet_block_backward(block, x, dout, temb_row=None, skip=None):
     a2 = n2(h, silu=True)
 
     # ---- conv2 and norm2 ----
-    da2, g = conv2d_backward(block.conv2, a2, dout)
+    da2, g = conv2d_backward(block.conv2, a2, dout, need_dw=base_grads)
     grads.update({"conv2." + k_: v for k_, v in g.items()})
     (dh,), dg2, db2 = ops.groupnorm_backward([h.t], da2, B, HW, n2.num_groups, g2, b2, n2.eps, [h.stats], act="silu")
     grads["norm2.weight"], grads["norm2.bias"] = dg2, db2
@@ -111,14 +120,14 @@ def resnet_block_backward(block, x, dout, temb_row=None, skip=None):
     dtemb_row = None
     if temb_row is not None:
         dtemb_row = _colsum_per_image(dh, B, HW)[:, :block.conv1.out_channels].contiguous()
-    da1, g = conv2d_backward(block.conv1, a1, dh)
+    da1, g = conv2d_backward(block.conv1, a1, dh, need_dw=base_grads)
     grads.update({"conv1." + k_: v for k_, v in g.items()})
 
     # ---- shortcut: its data gradient joins norm1's dx as ``dres`` ----
     if block.conv_shortcut is None:
         dsc = dout
     else:
-        dsc, g = conv2d_backward(block.conv_shortcut, x, dout, x2=skip)
+        dsc, g = conv2d_backward(block.conv_shortcut, x, dout, x2=skip, need_dw=base_grads)
         grads.update({"conv_shortcut." + k_: v for k_, v in g.items()})
     dxs, dg1, db1 = ops.groupnorm_backward([s.t for s in srcs], da1, B, HW, n1.num_groups, g1, b1, n1.eps,
                                            [s.stats for s in srcs], act="silu", dres=dsc)
@@ -162,12 +171,14 @@ def fused_proj_backward(fp, names, x, dout, need_dx=True, base_grads=True):
             grads[pre + ".weight"] = dW[n_off[i]:n_off[i + 1], :K].contiguous()
             if bases[i].bias is not None:
                 grads[pre + ".bias"] = colsum[n_off[i]:n_off[i + 1]].contiguous()
+    Wt, At = fp._cache_get((dtype, "dgrad"), lambda: (ops.pack_dgrad_weights(Wp, 1),
+                                                      None if A is None else ops.pack_dgrad_weights(A, 1)))
     if A is None:
-        dx = ops.conv2d_dgrad(dout, ops.pack_dgrad_weights(Wp, 1), 1, M, 1, C=Wp.shape[1]) if need_dx else None
+        dx = ops.conv2d_dgrad(dout, Wt, 1, M, 1, C=Wp.shape[1]) if need_dx else None
         return dx, grads
     Kp = Wp.shape[1] - LORA_PAD
     t = ops.linear(x, A)                                                  # recomputed [M, LORA_PAD]
-    dcat = ops.conv2d_dgrad(dout, ops.pack_dgrad_weights(Wp, 1), 1, M, 1, C=Wp.shape[1])
+    dcat = ops.conv2d_dgrad(dout, Wt, 1, M, 1, C=Wp.shape[1])
     dxb, dt = dcat[:, :Kp], dcat[:, Kp:]
     dBx = ops.conv2d_wgrad(t, dout, 1, M, 1)                              # [Ntot, LORA_PAD]
     dAbar = ops.conv2d_wgrad(x, dt, 1, M, 1)                              # [LORA_PAD, Kpad]
@@ -182,7 +193,7 @@ def fused_proj_backward(fp, names, x, dout, need_dx=True, base_grads=True):
             r0 += r
     dx = None
     if need_dx:   # dx = dx_part + dt Abar: the first addend rides on the second GEMM's residual input
-        dx = ops.conv2d_dgrad(dt, ops.pack_dgrad_weights(A, 1), 1, M, 1, C=A.shape[1], residual=dxb)
+        dx = ops.conv2d_dgrad(dt, At, 1, M, 1, C=A.shape[1], residual=dxb)
     return dx, grads
 
 
@@ -236,8 +247,8 @@ def feed_forward_backward(ff, x, dout, base_grads=True):
     dtype = x.dtype
     M = x.shape[0]
     g_out = geglu(x)                                                      # [M, 4C]
-    dg, g2 = linear_backward(lin, g_out, dout)
-    grads = {"net.2." + k_: v for k_, v in g2.items()} if base_grads else {}
+    dg, g2 = linear_backward(lin, g_out, dout, need_dw=base_grads)
+    grads = {"net.2." + k_: v for k_, v in g2.items()}
     dg = dg[:, :g_out.shape[1]] if dg.shape[1] != g_out.shape[1] else dg
     w, b = geglu._cache_get((dtype,), lambda: packing.pack_geglu_weight(
         geglu.proj.weight.detach().float(), geglu.proj.bias.detach().float(), dtype, ops.k_tile(dtype)))
@@ -251,7 +262,8 @@ def feed_forward_backward(ff, x, dout, base_grads=True):
         grads["net.0.proj.weight"] = torch.cat([dwi[0::2], dwi[1::2]], 0).contiguous()
         grads["net.0.proj.bias"] = torch.cat([dbi[0::2], dbi[1::2]], 0).contiguous()
         assert grads["net.0.proj.weight"].shape[0] == 2 * half
-    dx = ops.conv2d_dgrad(dpre, ops.pack_dgrad_weights(w, 1), 1, M, 1, C=w.shape[1])
+    wt = geglu._cache_get((dtype, "dgrad"), lambda: ops.pack_dgrad_weights(w, 1))
+    dx = ops.conv2d_dgrad(dpre, wt, 1, M, 1, C=w.shape[1])
     return dx, grads
 
 
@@ -317,8 +329,8 @@ def transformer2d_backward(tr, x, dout, ctx, Lk, kvs=None, base_grads=True):
         kv = None if kvs is None else kvs.get(id(blk.attn2))
         t = blk(t, B, L, ctx, Lk) if kv is None else _block_forward_kv(blk, t, B, L, Lk, kv)
     grads = {}
-    dt, g = conv2d_backward(tr.proj_out, x.like(t), dout)
-    grads.update({"proj_out." + k_: v for k_, v in g.items()} if base_grads else {})
+    dt, g = conv2d_backward(tr.proj_out, x.like(t), dout, need_dw=base_grads)
+    grads.update({"proj_out." + k_: v for k_, v in g.items()})
     C = t.shape[1]
     dkvs = []
     for i in reversed(range(len(tr.transformer_blocks))):
@@ -327,8 +339,8 @@ def transformer2d_backward(tr, x, dout, ctx, Lk, kvs=None, base_grads=True):
         dt, dkv, g = transformer_block_backward(blk, t_in[i], _cols(dt, C), B, L, ctx, Lk, kv=kv, base_grads=base_grads)
         grads.update({f"transformer_blocks.{i}." + k_: v for k_, v in g.items()})
         dkvs.insert(0, dkv)
-    dn, g = conv2d_backward(tr.proj_in, n, _cols(dt, C))
-    grads.update({"proj_in." + k_: v for k_, v in g.items()} if base_grads else {})
+    dn, g = conv2d_backward(tr.proj_in, n, _cols(dt, C), need_dw=base_grads)
+    grads.update({"proj_in." + k_: v for k_, v in g.items()})
     (dx,), dg, db = ops.groupnorm_backward([x.t], dn, B, L, tr.norm.num_groups, tr.norm.weight.detach().float(),
                                            tr.norm.bias.detach().float(), tr.norm.eps, [x.stats], act="none", dres=dout)
     grads["norm.weight"], grads["norm.bias"] = dg, db
@@ -446,9 +458,8 @@ def unet_backward(unet, sample, timesteps, ctx, Lk, dtaps, unet_block_indices, c
     if dsample is not None:
         _ensure_stats(h)
         a = unet.conv_norm_out(h, silu=True)
-        da, g = conv2d_backward(unet.conv_out, a, dsample)
-        if base_grads:
-            put("conv_out", g)
+        da, g = conv2d_backward(unet.conv_out, a, dsample, need_dw=base_grads)
+        put("conv_out", g)
         no = unet.conv_norm_out
         (dh,), dg, db = ops.groupnorm_backward([h.t], da, B, h.HW, no.num_groups, no.weight.detach().float(),
                                                no.bias.detach().float(), no.eps, [h.stats], act="silu")
@@ -463,9 +474,8 @@ def unet_backward(unet, sample, timesteps, ctx, Lk, dtaps, unet_block_indices, c
             dout = tape.pop(out.t)
             if dout is None:
                 continue
-            dx, dskip, dtr, g = resnet_block_backward(mod, x, dout, temb_row=rows[id(mod)], skip=skip)
-            if not base_grads:
-                g = {k_: v for k_, v in g.items() if k_.startswith("norm")}
+            dx, dskip, dtr, g = resnet_block_backward(mod, x, dout, temb_row=rows[id(mod)], skip=skip,
+                                                      base_grads=base_grads)
             put(names[id(mod)], g)
             drow[id(mod)] = dtr
             tape.add(x.t, dx.t)
@@ -489,16 +499,14 @@ def unet_backward(unet, sample, timesteps, ctx, Lk, dtaps, unet_block_indices, c
             dout = tape.pop(out.t)
             if dout is None:
                 continue
-            dx, g = conv2d_backward(conv, x, dout, upsample=ups)
-            if base_grads:
-                put(names[id(conv)], g)
+            dx, g = conv2d_backward(conv, x, dout, upsample=ups, need_dw=base_grads)
+            put(names[id(conv)], g)
             tape.add(x.t, dx)
         elif kind == "conv_in":
             _, conv, x, out = r_
             dout = tape.pop(out.t)
-            dx, g = conv2d_backward(conv, x, dout)
-            if base_grads:
-                put("conv_in", g)
+            dx, g = conv2d_backward(conv, x, dout, need_dw=base_grads)
+            put("conv_in", g)
             tape.add(x.t, dx)
     dsample_in = tape.pop(sample.t)
 
@@ -545,12 +553,11 @@ def unet_backward(unet, sample, timesteps, ctx, Lk, dtaps, unet_block_indices, c
         off += n
     ds = ops.conv2d_dgrad(drows_c, ops.pack_dgrad_weights(Wp, 1), 1, B, 1, C=Wp.shape[1])
     demb = ops.silu_backward(emb, _cols(ds, emb.shape[1]))
-    da1, g = linear_backward(te.linear_2, a1, demb)
+    da1, g = linear_backward(te.linear_2, a1, demb, need_dw=base_grads)
+    put("time_embedding.linear_2", g)
     if base_grads:
-        put("time_embedding.linear_2", g)
-    de1 = ops.silu_backward(e1, _cols(da1, e1.shape[1]))
-    _, g = linear_backward(te.linear_1, t_emb, de1, need_dx=False)
-    if base_grads:
+        de1 = ops.silu_backward(e1, _cols(da1, e1.shape[1]))
+        _, g = linear_backward(te.linear_1, t_emb, de1, need_dx=False)
         put("time_embedding.linear_1", g)
     return {"sample": dsample_in, "ctx": dctx, "cond_emb": ops.rows_to_f32(demb) if cond_emb is not None else None,
             "grads": grads}

@@ -302,16 +302,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         }
     }
     if (dgamma) {
+        // the four waves' column sums meet in LDS first: one global atomic per channel and BLOCK (the grid is capped at
+        // 128 blocks) -- one per wave of a 1024-block grid put 4096 adds on every address, 0.5 ms of serialised atomics
+        __shared__ float red[2 * 64 * MAXCH * EPC];
+        for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) red[c] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
             const int q = lane + 64 * i;
             if (q < CPR) {
 #pragma unroll
                 for (int j = 0; j < EPC; ++j) {
-                    unsafeAtomicAdd(dgamma + q * EPC + j, ag[i][j]);
-                    unsafeAtomicAdd(dbeta + q * EPC + j, ab[i][j]);
+                    atomicAdd(&red[q * EPC + j], ag[i][j]);
+                    atomicAdd(&red[C + q * EPC + j], ab[i][j]);
                 }
             }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            unsafeAtomicAdd(dgamma + c, red[c]);
+            unsafeAtomicAdd(dbeta + c, red[C + c]);
         }
     }
 }
@@ -425,7 +435,7 @@ int madm_layernorm_bwd(int dtype, const void* x, const void* dy, void* dx, int M
     MADM_REQUIRE(C % epc == 0, "layernorm_bwd: C=%d must be a multiple of %d", C, epc);
     MADM_REQUIRE(C / epc <= 64 * 5, "layernorm_bwd: C=%d too large (max %d)", C, 64 * 5 * epc);
     int blocks = (M + 3) / 4;
-    if (blocks > 1024) blocks = 1024;   // 4 096 waves, each adding its column sums once
+    if (blocks > 128) blocks = 128;   // every block adds its column sums once
     hipStream_t s = (hipStream_t)stream;
     if (C / epc <= 64 * 3)   // the UNet's widths in bf16 (320 / 640 / 1280): 3 chunks per lane keep the row state small
         MADM_DISPATCH_DTYPE(dtype, (layernorm_bwd_kernel<T, 3><<<dim3((unsigned)blocks), 256, 0, s>>>(

@@ -325,7 +325,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 #pragma unroll
     for (int j = 0; j < EPC; ++j) s[j] = 0.f;
     const T* xb = x + ((size_t)b * HW) * ldx + q * EPC;
-    for (int r = r0; r < r1; ++r) {
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {   // four independent row loads in flight
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)(r + u) * ldx);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float f[EPC];
+            chunk_to_f32<T>(v[u], f);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) s[j] += f[j];
+        }
+    }
+    for (; r < r1; ++r) {
         float f[EPC];
         chunk_to_f32<T>(*reinterpret_cast<const uint4*>(xb + (size_t)r * ldx), f);
 #pragma unroll
@@ -368,8 +381,8 @@ extern "C" int madm_colsum(int dtype, const void* x, int ldx, int B, int HW, int
     MADM_REQUIRE(x && out && B > 0 && HW > 0 && C > 0, "colsum: bad argument");
     const int epc = dtype == MADM_BF16 ? 8 : 4;
     MADM_REQUIRE(C % epc == 0 && ldx % epc == 0 && ldx >= C, "colsum: C / ldx must be multiples of %d elements", epc);
-    int slices = (HW + 255) / 256;
-    if (slices > 1024) slices = 1024;
+    int slices = (HW + 31) / 32;
+    if (slices > 512) slices = 512;
     const int rows_per_slice = (HW + slices - 1) / slices;
     slices = (HW + rows_per_slice - 1) / rows_per_slice;
     MADM_REQUIRE(B <= 65535, "colsum: too many images");

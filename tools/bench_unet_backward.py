@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--hw", type=int, default=64)
+    ap.add_argument("--mode", default="", help="fwd | lora | all: run only this leg (for rocprofv3 --kernel-trace)")
     args = ap.parse_args()
     from madm_amd import backward, ops, weights
     from madm_amd.nn import Tok
@@ -62,6 +63,12 @@ def main():
             best = min(best, max(e0.elapsed_time(e1), (time.perf_counter() - t0) * 1e3))
         return best
 
+    if args.mode:
+        fn = {"fwd": lambda: unet(x, ts, ctx, Lk, cond_emb=cond, unet_block_indices=taps),
+              "lora": lambda: backward.unet_backward(unet, x, ts, ctx, Lk, dtaps, taps, cond_emb=cond, base_grads=False),
+              "all": lambda: backward.unet_backward(unet, x, ts, ctx, Lk, dtaps, taps, cond_emb=cond, base_grads=True)}[args.mode]
+        print(f"{args.mode}: {timed(fn):.1f} ms (eager, best of {args.reps})")
+        return
     t_f = timed(lambda: unet(x, ts, ctx, Lk, cond_emb=cond, unet_block_indices=taps))
     t_l = timed(lambda: backward.unet_backward(unet, x, ts, ctx, Lk, dtaps, taps, cond_emb=cond, base_grads=False))
     t_a = timed(lambda: backward.unet_backward(unet, x, ts, ctx, Lk, dtaps, taps, cond_emb=cond, base_grads=True))
