@@ -292,11 +292,54 @@ class LdmRocm(nn.Module):
             return t
         return 0.02 * torch.randn(*self.uncond_inputs_size, generator=torch.Generator().manual_seed(4242))
 
-    @torch.no_grad()
     def forward(self, batched_inputs, input_modal, **kwargs):
         # two stages with a narrow hand-over (the noisy latents), so that a serving loop can capture / schedule them
         # separately (measured: free-running whole forwards on two streams beat the strict encoder || UNet pipeline)
-        return self._stage_unet(self._stage_encode(batched_inputs), batched_inputs, **kwargs)
+        want_grad = torch.is_grad_enabled() and self._wants_grad(batched_inputs, kwargs)
+        with torch.no_grad():
+            st = self._stage_encode(batched_inputs)
+            out = self._stage_unet(st, batched_inputs, _keep_for_grad=want_grad, **kwargs)
+        if not want_grad:
+            return out
+        return self._attach_unet_grad(out, batched_inputs, kwargs)
+
+    # ---- training: the UNet stage as one autograd node ("differentiable w.r.t. its requires_grad
+    #      params through standard autograd") ----
+    def _wants_grad(self, batched_inputs, kwargs):
+        if kwargs.get('ema_forward') and hasattr(self, 'ema_unet'):
+            return False
+        if kwargs.get("_return_tokens", False) or batched_inputs.get("return_unet_feats"):
+            return False   # the HIP backbone's token hand-over has no backward yet
+        t = batched_inputs['cond_inputs'], batched_inputs['cond_emb']
+        return any(x is not None and torch.is_tensor(x) and x.requires_grad for x in t) or \
+            any(p.requires_grad for p in self.unet.parameters())
+
+    def _attach_unet_grad(self, out, batched_inputs, kwargs):
+        """Re-issues the UNet taps (and the final sample, when it was asked for) as outputs of ``_UNetTapsFn``: the
+        values are the ones the forward just computed, the node's backward is ``backward.unet_backward``."""
+        keep = self._grad_keep
+        self._grad_keep = None
+        extra = None
+        if isinstance(out, tuple):
+            feats, extra = out
+        else:
+            feats = out
+        n_enc = keep["n_enc"]
+        n_taps = len(keep["taps"])
+        with_sample = isinstance(extra, dict)
+        named = [(n, p) for n, p in self.unet.named_parameters() if p.requires_grad]
+        keep["param_names"] = [n for n, _ in named]
+        keep["with_sample"] = with_sample
+        values = list(feats[n_enc:n_enc + n_taps]) + ([extra['before_vae.decoder']] if with_sample else [])
+        outs = _UNetTapsFn.apply(keep, batched_inputs['cond_inputs'], batched_inputs['cond_emb'], len(values), *values,
+                                 *[p for _, p in named])
+        feats = list(feats)
+        feats[n_enc:n_enc + n_taps] = outs[:n_taps]
+        if with_sample:
+            extra = dict(extra)
+            extra['before_vae.decoder'] = outs[n_taps]
+            return feats, extra
+        return feats if extra is None else (feats, extra)
 
     def _stage_encode(self, batched_inputs):
         """normalise -> vae_encoder -> timestep draw -> add_noise (ldm_diffusers.py:143-163); returns the hand-over."""
@@ -343,6 +386,12 @@ class LdmRocm(nn.Module):
             forward_unet = self.unet
         sample, unet_taps = _unet_tokens(forward_unet, Tok(noisy, B, h, w), timesteps, text_prompt,
                                          res_time_embedding, self.unet_block_indices, self.unet_block_indices_type)
+        if kwargs.pop("_keep_for_grad", False):
+            if self.unet_block_indices_type != "after":
+                raise NotImplementedError("autograd through 'in'-type taps")
+            self._grad_keep = {"unet": forward_unet, "noisy": noisy, "B": B, "h": h, "w": w, "timesteps": timesteps,
+                               "indices": tuple(self.unet_block_indices), "taps": [t_.C for t_ in unet_taps],
+                               "n_enc": len(enc_taps), "dtype": dtype}
 
         # feature lists as channels-last Toks; converted to NCHW f32 at the API boundary unless the (HIP) backbone
         # asked for tokens (madm_amd.backbone passes _return_tokens=True)
@@ -361,6 +410,8 @@ class LdmRocm(nn.Module):
             # taps of the decoder run on the (scaled) latents, not on the UNet output (:204-205)
             lat_tok = Tok(ops.nchw_to_nhwc(latents, dtype, ops.k_tile(dtype)), B, h, w)
             _, dec_tok = self.vae.decode(lat_tok, tuple(self.decoder_block_indices), output_final=False)
+        if getattr(self, "_grad_keep", None) is not None:
+            self._grad_keep["n_enc"] = len(enc_tok)
         if minmax is not None and self.check_input_range and not torch.cuda.is_current_stream_capturing():
             lo, hi = minmax.tolist()  # the reference's range assert (:147); one sync per call, like there
             assert -1 <= lo and hi <= 1
@@ -386,6 +437,63 @@ class LdmRocm(nn.Module):
             }
         else:
             return feats
+
+
+class _UNetTapsFn(torch.autograd.Function):
+    """The UNet stage of LdmRocm as ONE autograd node: forward hands back the tap tensors the (no-grad) HIP forward
+    already produced; backward runs ``backward.unet_backward`` (block interiors recomputed) and returns the gradients of
+    the prompt tokens, the time-embedding residual and every trainable UNet parameter."""
+
+    @staticmethod
+    def forward(ctx, keep, cond_inputs, cond_emb, n_values, *rest):
+        ctx.keep = keep
+        ctx.cond_shape = None if cond_emb is None else tuple(cond_emb.shape)
+        ctx.n_values = n_values
+        ctx.save_for_backward(cond_inputs, *([] if cond_emb is None else [cond_emb]))
+        return tuple(v.clone() for v in rest[:n_values])
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from . import backward as bw
+        k = ctx.keep
+        unet, dtype, B, h, w = k["unet"], k["dtype"], k["B"], k["h"], k["w"]
+        saved = ctx.saved_tensors
+        cond_inputs = saved[0]
+        cond_emb = saved[1] if len(saved) > 1 else None
+        n_taps = len(k["taps"])
+        kt = ops.k_tile(dtype)
+
+        def tokens(g, cpad=None):   # NCHW f32 gradient -> channels-last tokens of the compute dtype
+            return ops.nchw_to_nhwc(g.float().contiguous(), dtype, cpad if cpad is not None else g.shape[1])
+
+        dtaps = [tokens(gouts[i]) for i in range(n_taps)]   # autograd materialises zeros for unused outputs
+        dsample = None
+        if k["with_sample"] and gouts[n_taps] is not None:
+            dsample = tokens(gouts[n_taps], cpad=unet.conv_out.n_pad)
+        Lk = cond_inputs.shape[1]
+        ctx_tok = ops.cast_from_f32(cond_inputs.detach().float().contiguous().view(B * Lk, cond_inputs.shape[2]), dtype)
+        cond = None
+        if cond_emb is not None:
+            cond = cond_emb.detach()
+            if cond.dim() == 3 and cond.shape[1] == 1:
+                cond = cond[:, 0]
+            cond = cond.float().contiguous()
+        names = k["param_names"]
+        base = any(".lora_" not in n for n in names)
+        res = bw.unet_backward(unet, Tok(k["noisy"], B, h, w), k["timesteps"], ctx_tok, Lk, dtaps, k["indices"],
+                               cond_emb=cond, dsample=dsample, base_grads=base)
+        g_ctx = None
+        if cond_inputs.requires_grad:
+            g_ctx = ops.rows_to_f32(res["ctx"])[:, :cond_inputs.shape[2]].reshape(cond_inputs.shape).to(cond_inputs.dtype)
+        g_cond = None
+        if cond_emb is not None and cond_emb.requires_grad:
+            g_cond = res["cond_emb"].reshape(ctx.cond_shape).to(cond_emb.dtype)
+        params = dict(unet.named_parameters())
+        g_params = []
+        for n in names:
+            g = res["grads"].get(n)
+            g_params.append(None if g is None else g.reshape(params[n].shape).to(params[n].dtype))
+        return (None, g_ctx, g_cond, None) + (None,) * ctx.n_values + tuple(g_params)
 
 
 weights_loader = weights

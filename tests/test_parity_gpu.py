@@ -261,3 +261,60 @@ def test_unet_backward_equals_oracle_autograd(cuda, dtype, lora):
     ranked = sorted(results, key=lambda t: -float(t[1].split("l2 ")[1]))
     print(dtype, "lora" if lora else "plain", len(results), "tensors; worst three:", [m for _, m in ranked[:3]])
     assert not bad, bad[:8]
+
+
+def test_ldm_rocm_is_differentiable_through_autograd(cuda):
+    """the extractor is an nn.Module whose output is differentiable w.r.t. its requires_grad parameters
+    and the conditioning inputs through standard autograd.  LdmRocm.forward under grad mode returns taps that hang on
+    ONE autograd node (_UNetTapsFn) whose backward is backward.unet_backward: loss.backward() fills .grad of the active
+    LoRA matrices, the prompt tokens and the time-embedding residual with exactly what the explicit call returns."""
+    from madm_amd import backward, ops
+    from madm_amd.ldm_rocm import LdmRocm
+    from madm_amd.nn import Tok
+    m = LdmRocm("", [], [5, 8, 11], [], input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
+                compute_dtype=torch.float32, weights='synthetic', seed=0)
+    add_lora(m.unet, _LoraConfig)
+    for n, p in m.unet.named_parameters():
+        p.requires_grad = ".lora_" in n and ".Depth." in n
+    case = CASES["small_lora"]
+    images, cond_inputs, cond_emb, _, _ = make_inputs(**case)
+    ci = cond_inputs.cuda().requires_grad_(True)
+    ce = cond_emb.cuda().requires_grad_(True)
+    t = case["t"]
+    inputs = {"img": images.cuda(), "cond_inputs": ci, "cond_emb": ce, "timestep": (t, t + 1)}
+    feats = m(inputs, "rgb")
+    assert len(feats) == 3 and all(f.requires_grad for f in feats)
+    _compare("small_lora", (m.last_latents.cpu(), m.last_sample.nchw(4).cpu(), [f.detach().cpu() for f in feats]),
+             load_golden("small_lora"), torch.float32)     # same values as the no-grad forward
+    g = torch.Generator().manual_seed(5)
+    gs = [torch.randn(f.shape, generator=g).cuda() for f in feats]
+    sum((f * g_).sum() for f, g_ in zip(feats, gs)).backward()
+
+    with torch.no_grad():
+        st = m._stage_encode(inputs)
+        B, h, w = st["B"], st["h"], st["w"]
+        Lk = cond_inputs.shape[1]
+        ctx = ops.cast_from_f32(cond_inputs.cuda().view(B * Lk, 768), torch.float32)
+        res = backward.unet_backward(m.unet, Tok(st["noisy"], B, h, w), st["timesteps"], ctx, Lk,
+                                     [ops.nchw_to_nhwc(g_, torch.float32, g_.shape[1]) for g_ in gs], (5, 8, 11),
+                                     cond_emb=cond_emb.cuda()[:, 0].contiguous(), base_grads=False)
+    torch.cuda.synchronize()
+    assert rel_err(ci.grad.cpu(), res["ctx"].cpu()[:, :768].reshape(ci.shape))[0] < 1e-5
+    assert rel_err(ce.grad.cpu(), res["cond_emb"].cpu().reshape(ce.shape))[0] < 1e-5
+    n_checked = 0
+    for n, p in m.unet.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None, n
+            if "mid_block" in n and ".attn1.to_" in n and (".to_q." in n or ".to_k." in n):
+                # 1x1 map: softmax over one key, dq = dk = 0 -- rounding noise whose low bits depend on atomics order
+                assert float(p.grad.abs().max()) < 1e-4 and float(res["grads"][n].abs().max()) < 1e-4, n
+            else:
+                assert rel_err(p.grad.cpu(), res["grads"][n].cpu().reshape(p.shape))[0] < 1e-5, n
+            n_checked += 1
+        else:
+            assert p.grad is None, n
+    assert n_checked == 128 * 2
+    # without grad mode nothing is recorded
+    with torch.no_grad():
+        feats2 = m(inputs, "rgb")
+    assert not any(f.requires_grad for f in feats2)
