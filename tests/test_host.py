@@ -67,6 +67,64 @@ def test_argument_validation_reports_errors_without_gpu():
     assert lib.madm_groupnorm_stats(0, p, 1, 1, 6, p, None) == -1     # C not a multiple of 4
 
 
+def _header_struct_fields(struct_name):
+    hdr = open(os.path.join(ROOT, "include", "madm_hip.h")).read()
+    end = hdr.index("} " + struct_name + ";")
+    body = hdr[hdr.rindex("typedef struct {", 0, end):end]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.replace("typedef struct {", "").strip()
+        if decl:
+            fields.extend(re.sub(r"[\*\s]", "", n.split()[-1]) for n in decl.split(","))
+    return fields
+
+
+def test_gradient_struct_layouts_match_header():
+    from madm_amd import _lib
+    assert _header_struct_fields("madm_conv2d_wgrad_args") == [f[0] for f in _lib.Conv2dWgradArgs._fields_]
+    assert _header_struct_fields("madm_attention_bwd_args") == [f[0] for f in _lib.AttentionBwdArgs._fields_]
+    assert _header_struct_fields("madm_attention_args") == [f[0] for f in _lib.AttentionArgs._fields_]
+
+
+def test_gradient_entry_points_validate_arguments_without_gpu():
+    from madm_amd._lib import lib, Conv2dWgradArgs, AttentionBwdArgs
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.addressof(buf)
+    a = Conv2dWgradArgs()
+    assert lib.madm_conv2d_wgrad(ctypes.byref(a), None) == -1 and b"null argument" in lib.madm_last_error()
+    a.in1 = a.dout = a.dw = p
+    a.dtype, a.C1, a.N = 1, 12, 8
+    a.B = a.IH = a.IW = a.OH = a.OW = a.KH = a.KW = a.stride = 1
+    assert lib.madm_conv2d_wgrad(ctypes.byref(a), None) == -1 and b"multiples of 8" in lib.madm_last_error()
+    a.C1, a.N = 16, 6
+    assert lib.madm_conv2d_wgrad(ctypes.byref(a), None) == -1 and b"multiple of 4" in lib.madm_last_error()
+    b = AttentionBwdArgs()
+    for f in ("q", "k", "v", "o", "dout", "dq", "dk", "dv"):
+        setattr(b, f, p)
+    b.dtype, b.B, b.H, b.Lq, b.Lk, b.D = 1, 1, 2, 4, 4, 40
+    b.ldq = b.ldk = b.ldv = b.ldo = b.lddo = b.lddq = b.lddk = b.lddv = 80
+    assert lib.madm_attention_bwd_workspace_bytes(ctypes.byref(b)) == 2 * 1 * 2 * 4 * 4
+    assert lib.madm_attention_bwd(ctypes.byref(b), None) == -1 and b"workspace" in lib.madm_last_error()
+    b.workspace, b.workspace_bytes, b.D = p, 64, 48
+    b.ldq = b.ldk = b.ldv = b.ldo = b.lddo = b.lddq = b.lddk = b.lddv = 96
+    assert lib.madm_attention_bwd(ctypes.byref(b), None) == -2 and b"not instantiated" in lib.madm_last_error()
+    assert lib.madm_layernorm_bwd(1, p, p, p, 4, 12, p, 1e-5, None, None, None, None) == -1   # C not a multiple of 8
+    assert lib.madm_geglu_bwd(1, p, p, p, 1, 12, None) == -1
+    assert lib.madm_colsum(1, p, 8, 1, 1, 12, p, None) == -1
+
+
+def test_weight_gradient_unpacking_inverts_the_weight_packing():
+    from madm_amd import packing
+    w = torch.randn(8, 96, 3, 3)
+    for splits, kt in ((None, 32), ([64, 32], 32), ([40, 56], 64)):
+        p = packing.pack_conv_weight(w, torch.float32, kt, splits=splits)
+        back = packing.unpack_conv_weight_grad(p, 96, 3, 3, kt, splits=splits)
+        assert torch.equal(back, w), (splits, kt)
+    w5 = torch.randn(4, 5, 3, 3)   # tiny channel count: the padding channels are dropped
+    assert torch.equal(packing.unpack_conv_weight_grad(packing.pack_conv_weight(w5, torch.float32, 32), 5, 3, 3, 32), w5)
+
+
 def test_ops_refuse_cpu_tensors():
     from madm_amd import ops
     x = torch.zeros(4, 64)
