@@ -2,7 +2,8 @@
 NO data-path collective (replicas only -- GroupNorm/LayerNorm are per-sample, the
 reference's evaluator does not reduce across ranks either, evaluation/d2_evaluator.py:228-238).
 torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" on CPU) is used for the barrier and the
-max-over-ranks of the timed region only."""
+max-over-ranks of the timed region only.  The training path's single exchange step -- the gradient all-reduce --
+is GradBucketReducer below."""
 import os
 
 import torch
@@ -51,3 +52,45 @@ def sum_over_ranks(value, dist=None, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.item()
+
+
+class GradBucketReducer:
+    """The ONE exchange step of the training path: all-reduce(mean) of the gradients, here over
+    the flat fp32 gradient buffer of ``optim.FlatParams`` in a few large contiguous buckets instead of DDP's per-tensor
+    buckets -- xGMI is point-to-point (7 links x ~153 GB/s per GPU), a ring all-reduce is per-link bound, so fewer and
+    larger messages win; 64 Mi floats (256 MB) per bucket keeps 13 buckets in flight for the full fine-tune (3.46 GB)
+    and a single one for the LoRA mode (~32 MB).  ``reduce_range`` may be called as soon as a span of the buffer is
+    final (the explicit backward fills it back to front), the collectives run asynchronously on the backend's stream
+    and ``finish`` waits for them and applies the 1 / world scale.  Replaces torch DistributedDataParallel
+    (engine/defaults.py: create_ddp_model) for the flat-buffer layout; no-op for world size 1."""
+
+    def __init__(self, flat_grad, dist=None, bucket_numel=64 << 20):
+        assert flat_grad.dim() == 1 and flat_grad.is_contiguous()
+        self.g, self.dist, self.bucket = flat_grad, dist, int(bucket_numel)
+        self.world = 1 if dist is None else dist.get_world_size()
+        self.handles = []
+        self.done_lo = flat_grad.numel()
+
+    def reduce_range(self, lo, hi):
+        """Starts the all-reduce of g[lo:hi] in bucket-sized pieces (async)."""
+        if self.dist is None or self.world == 1:
+            return
+        for a in range(lo, hi, self.bucket):
+            b = min(a + self.bucket, hi)
+            self.handles.append(self.dist.all_reduce(self.g[a:b], op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def reduce_tail(self, lo):
+        """Everything from ``lo`` to the last span already handed over is final: reduce it (back-to-front use)."""
+        if lo < self.done_lo:
+            self.reduce_range(lo, self.done_lo)
+            self.done_lo = lo
+
+    def finish(self):
+        """Reduces whatever has not been handed over yet, waits, and turns the sums into means."""
+        self.reduce_tail(0)
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.done_lo = self.g.numel()
+        if self.world > 1:
+            self.g.mul_(1.0 / self.world)

@@ -63,3 +63,47 @@ def test_single_process_is_passthrough():
     from madm_amd import dist as mdist
     os.environ.pop("WORLD_SIZE", None)
     assert mdist.max_over_ranks(3.5) == 3.5 and mdist.sum_over_ranks(2) == 2.0
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from madm_amd import dist as mdist
+    d = mdist.init(backend="gloo")
+    n = 1000
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)          # rank r holds (r + 1) * [0, 1, 2, ...]
+    red = mdist.GradBucketReducer(g, d, bucket_numel=96)           # ragged: 1000 = 10 * 96 + 40
+    red.reduce_tail(700)                                           # the explicit backward fills the buffer back to front
+    red.reduce_tail(250)
+    red.finish()
+    q.put((rank, g.clone()))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_gradient_all_reduce_mean_two_rank_gloo():
+    """The training path's one exchange step: bucketed all-reduce(mean) of the flat gradient buffer, handed over in
+    back-to-front spans; every rank ends with the mean of the ranks' gradients, every element reduced exactly once."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((r, g) for r, g in (q.get(timeout=120) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.arange(1000, dtype=torch.float32) * 1.5           # mean of 1x and 2x
+    for _, g in res:
+        assert torch.equal(g, want)
+
+
+def test_gradient_reducer_is_a_no_op_for_one_rank():
+    from madm_amd.dist import GradBucketReducer
+    g = torch.arange(10, dtype=torch.float32)
+    red = GradBucketReducer(g, None)
+    red.reduce_tail(4)
+    red.finish()
+    assert torch.equal(g, torch.arange(10, dtype=torch.float32))
