@@ -70,6 +70,9 @@ class FlatAdamW:
         check(lib.madm_adamw_step(self.flat.flat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                   self.flat.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                   self.step_count, scale, _stream()), "madm_adamw_step")
+        # the kernel wrote through raw pointers: move the parameters' version counters like an in-place torch op would,
+        # so the packed device operands derived from them (nn._Packed caches) are re-derived on the next forward
+        torch.autograd.graph.increment_version(self.flat.params)
         return norm
 
 

@@ -318,3 +318,44 @@ def test_ldm_rocm_is_differentiable_through_autograd(cuda):
     with torch.no_grad():
         feats2 = m(inputs, "rgb")
     assert not any(f.requires_grad for f in feats2)
+
+
+def test_extractor_training_step_lora(cuda):
+    """train.ExtractorTrainer: HIP forward -> torch loss -> autograd through the UNet node -> flat-buffer clip + AdamW +
+    EMA (engine/train_loop.py:203-217, cmdise.py:337-349).  Only the active LoRA matrices move, the first update equals
+    torch.optim.AdamW on the same gradients, and a few steps on a fixed batch reduce the loss."""
+    from madm_amd.ldm_rocm import LdmRocm
+    from madm_amd.train import ExtractorTrainer
+    m = LdmRocm("", [], [5, 8, 11], [], input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
+                compute_dtype=torch.float32, weights='synthetic', seed=0)
+    add_lora(m.unet, _LoraConfig)
+    for n, p in m.unet.named_parameters():
+        p.requires_grad = ".lora_" in n and ".Depth." in n
+    frozen = {n: p.detach().clone() for n, p in m.unet.named_parameters() if not p.requires_grad and "down_blocks.0" in n}
+    case = CASES["small_lora"]
+    images, cond_inputs, cond_emb, _, _ = make_inputs(**case)
+    t = case["t"]
+    batch = {"img": images.cuda(), "cond_inputs": cond_inputs.cuda(), "cond_emb": cond_emb.cuda(), "timestep": (t, t + 1)}
+    with torch.no_grad():
+        target = [f.clone() * 0.9 for f in m(batch, "rgb")]
+
+    def loss_fn(feats):
+        return sum(((f - g_) ** 2).mean() for f, g_ in zip(feats, target))
+
+    lr = 2e-5   # Adam moves every element by ~lr per step: small against the LoRA entries (~0.04), linear regime
+    tr = ExtractorTrainer(m, lr=lr, weight_decay=0.0, clip_grad=1.0, ema_alpha=0.9)
+    before = tr.flat.flat.clone()
+    l0, norm = tr.step(batch, loss_fn)
+    assert norm is not None and norm > 0 and float(tr.flat.grad.abs().max()) > 0
+    # first AdamW step with clipping == torch.optim.AdamW on the same (clipped) gradient
+    ref_p = before.clone().requires_grad_(True)
+    ref_p.grad = tr.flat.grad.clone() * min(1.0, 1.0 / (norm + 1e-6))
+    torch.optim.AdamW([ref_p], lr=lr, weight_decay=0.0).step()
+    assert rel_err((tr.flat.flat - before).cpu(), (ref_p.detach() - before).cpu())[0] < 1e-3   # the update itself
+    assert rel_err(tr.ema.cpu(), (0.9 * before + 0.1 * tr.flat.flat).cpu())[0] < 1e-6
+    losses = [l0] + [tr.step(batch, loss_fn)[0] for _ in range(4)]
+    print("losses", [f"{v:.5f}" for v in losses])
+    assert losses[1] < losses[0] and losses[-1] < losses[0], losses
+    for n, p in m.unet.named_parameters():
+        if n in frozen:
+            assert torch.equal(p.detach(), frozen[n]), n
