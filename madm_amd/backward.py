@@ -1,15 +1,22 @@
-"""Backward passes composed from the C-ABI gradient kernels (first slice).
+"""Backward passes composed from the C-ABI gradient kernels.
 
 The reference trains through torch autograd (``losses.backward()``, engine/train_loop.py:203-217); here the gradient of
 a module is an explicit function over the same channels-last ``Tok`` tensors its forward uses, built from
-``madm_conv2d_wgrad`` / the forward conv on repacked weights (data gradient) / ``madm_groupnorm_bwd_*`` /
-``madm_layernorm_bwd``.  Activations are RECOMPUTED from the block input (the forward keeps nothing but what its caller
-holds), which is also how the 288 GB budget would be spent at bs = 2: no activation stash at all.
+``madm_conv2d_wgrad`` / the forward conv on repacked weights (data gradient) / ``madm_attention_bwd`` /
+``madm_groupnorm_bwd_*`` / ``madm_layernorm_bwd`` / ``madm_geglu_bwd``.  Activations are RECOMPUTED from the block input
+(the forward keeps nothing but what its caller holds): ``unet_backward`` re-runs the forward keeping only block inputs
+and every block's backward recomputes its interior -- no activation stash beyond ~40 block-boundary tensors.
 
-Parameter gradients come back as ``{parameter name: f32 tensor in the nn.Parameter's own shape}`` -- what a
-``FlatParams`` gradient buffer (madm_amd/optim.py) takes.  Built so far: Conv2d (stride 1 / stride 2 with both paddings /
-nearest-2x upsample), Linear, GroupNorm(+act), LayerNorm and diffusers' ResnetBlock2D (ldm_diffusers.py:290,333,387,435
-call sites); the transformer blocks (attention backward) and the autograd wiring of the whole UNet are not.
+Parameter gradients come back as ``{parameter name: f32 tensor in the nn.Parameter's own shape}``; ``ldm_rocm._UNetTapsFn``
+hands them to torch autograd (``p.grad``), ``train.ExtractorTrainer`` accumulates them into an ``optim.FlatParams`` buffer.
+Levels, each tested against torch autograd (tests/test_ops_gpu.py, tests/test_parity_gpu.py):
+  conv2d_backward (stride 1 / stride 2 with both paddings / nearest-2x upsample), linear_backward,
+  resnet_block_backward (diffusers ResnetBlock2D; ldm_diffusers.py:290,333,387,435 call sites),
+  fused_proj_backward (fused QKV GEMM with the peft LoRA K-extension, mtmadise.py:115-147), attention_module_backward,
+  feed_forward_backward (GEGLU), transformer_block_backward, transformer2d_backward,
+  unet_backward (ldm_diffusers.py:454-616 with 'after' taps :442-445).
+Not here: the backward of the HIP projections / DAFormer head and of the VAE (frozen, never differentiated by the
+reference's extractor: ldm_diffusers.py:283-311 runs under no_grad semantics for the encoder input).
 """
 import torch
 
