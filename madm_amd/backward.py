@@ -15,8 +15,8 @@ Levels, each tested against torch autograd (tests/test_ops_gpu.py, tests/test_pa
   fused_proj_backward (fused QKV GEMM with the peft LoRA K-extension, mtmadise.py:115-147), attention_module_backward,
   feed_forward_backward (GEGLU), transformer_block_backward, transformer2d_backward,
   unet_backward (ldm_diffusers.py:454-616 with 'after' taps :442-445).
-Not here: the backward of the HIP projections / DAFormer head and of the VAE (frozen, never differentiated by the
-reference's extractor: ldm_diffusers.py:283-311 runs under no_grad semantics for the encoder input).
+Not here: the backward of the HIP projections / DAFormer head, and of the VAE -- its parameters are frozen
+(LdmDiffusers._freeze) and its input images do not require grad, so the reference's autograd never enters it either.
 """
 import torch
 
