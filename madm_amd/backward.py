@@ -18,6 +18,8 @@ Levels, each tested against torch autograd (tests/test_ops_gpu.py, tests/test_pa
 Not here: the backward of the HIP projections / DAFormer head, and of the VAE -- its parameters are frozen
 (LdmDiffusers._freeze) and its input images do not require grad, so the reference's autograd never enters it either.
 """
+from types import SimpleNamespace
+
 import torch
 
 from . import ops, packing
@@ -375,16 +377,10 @@ class _Tape:
         return self.g.pop(t.data_ptr(), None)
 
 
-def unet_backward(unet, sample, timesteps, ctx, Lk, dtaps, unet_block_indices, cond_emb=None, dsample=None,
-                  base_grads=True):
-    """Backward of ``sd_unet.UNet2DConditionModel.forward(sample, timesteps, ctx, Lk, cond_emb, unet_block_indices,
-    'after')`` for the gradients ``dtaps`` of the tapped features ([M_i, C_i] tensors, same order) and, optionally,
-    ``dsample`` of the final sample ([M, n_pad]).  The forward is re-run here block by block (only block INPUTS are
-    kept; each block's backward recomputes its interior), then walked in reverse.
-
-    Returns {"sample": d latents [M, Cpad], "ctx": d prompt tokens [B*Lk, 768], "cond_emb": f32 [B, 1280] or None,
-    "grads": {parameter name: f32 gradient}} -- with ``base_grads=False`` (the reference's LoRA mode) only LoRA A / B,
-    the norms' affine parameters and the time-row projections come back."""
+def unet_forward_recorded(unet, sample, timesteps, ctx, Lk, unet_block_indices, cond_emb=None):
+    """``sd_unet.UNet2DConditionModel.forward(sample, timesteps, ctx, Lk, cond_emb, unet_block_indices, 'after')`` run block
+    by block while recording every block's INPUT on a tape (block interiors are not kept).  Returns
+    (sample_out Tok, tapped features list[Tok], state for :func:`unet_backward_from_state`)."""
     from .sd_unet import CtxKV
     dtype = sample.t.dtype
     B = sample.B
@@ -448,6 +444,24 @@ def unet_backward(unet, sample, timesteps, ctx, Lk, dtaps, unet_block_indices, c
                 x_in = h
                 h = u(h)
                 rec.append(("conv", u.conv, x_in, h, True))
+    out = unet.conv_out(h, norm=unet.conv_norm_out, stats=False)
+    st = SimpleNamespace(unet=unet, sample=sample, ctx=ctx, Lk=Lk, cond_emb=cond_emb, dtype=dtype, B=B, names=names,
+                         tape=tape, rows=rows, kvs=kvs, emb=emb, e1=e1, a1=a1, t_emb=t_emb, h=h, tapped=tapped)
+    return out, tapped, st
+
+
+def unet_backward_from_state(st, dtaps, dsample=None, base_grads=True):
+    """Reverse walk over the tape of :func:`unet_forward_recorded` for the gradients ``dtaps`` of the tapped features
+    ([M_i, C_i] tensors, same order) and, optionally, ``dsample`` of the final sample ([M, n_pad]); every block's
+    backward recomputes its interior.
+
+    Returns {"sample": d latents [M, Cpad], "ctx": d prompt tokens [B*Lk, 768], "cond_emb": f32 [B, 1280] or None,
+    "grads": {parameter name: f32 gradient}} -- with ``base_grads=False`` (the reference's LoRA mode) only LoRA A / B,
+    the norms' affine parameters and the time-row projections come back."""
+    unet, sample, ctx, Lk, cond_emb, dtype, B, names = st.unet, st.sample, st.ctx, st.Lk, st.cond_emb, st.dtype, st.B, st.names
+    tape, rows, kvs, emb, e1, a1, t_emb, h, tapped = st.tape, st.rows, st.kvs, st.emb, st.e1, st.a1, st.t_emb, st.h, st.tapped
+    rec = tape.records
+    te = unet.time_embedding
     assert len(tapped) == len(dtaps)
     for tk, g in zip(tapped, dtaps):
         tape.add(tk.t, g)
@@ -568,3 +582,10 @@ def unet_backward(unet, sample, timesteps, ctx, Lk, dtaps, unet_block_indices, c
         put("time_embedding.linear_1", g)
     return {"sample": dsample_in, "ctx": dctx, "cond_emb": ops.rows_to_f32(demb) if cond_emb is not None else None,
             "grads": grads}
+
+
+def unet_backward(unet, sample, timesteps, ctx, Lk, dtaps, unet_block_indices, cond_emb=None, dsample=None,
+                  base_grads=True):
+    """:func:`unet_forward_recorded` + :func:`unet_backward_from_state` in one call (see there)."""
+    _, _, st = unet_forward_recorded(unet, sample, timesteps, ctx, Lk, unet_block_indices, cond_emb=cond_emb)
+    return unet_backward_from_state(st, dtaps, dsample=dsample, base_grads=base_grads)

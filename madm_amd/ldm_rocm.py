@@ -152,8 +152,9 @@ def _tap_nchw(t):
     return t.nchw()
 
 
-def _unet_tokens(unet, x, timestep, encoder_hidden_states, res_time_embedding, unet_block_indices,
-                 unet_block_indices_type):
+def _unet_inputs(x, timestep, encoder_hidden_states, res_time_embedding):
+    """The reference's argument forms -> (int64 timesteps [B], prompt tokens [B*Lk, 768] of the compute dtype, Lk,
+    f32 time-embedding residual [B, 1280] or None)."""
     dtype = x.t.dtype
     B = x.B
     if not torch.is_tensor(timestep):
@@ -169,6 +170,12 @@ def _unet_tokens(unet, x, timestep, encoder_hidden_states, res_time_embedding, u
         if cond.dim() == 3 and cond.shape[1] == 1:
             cond = cond[:, 0]
         cond = cond.float().contiguous()
+    return timestep, ctx, Lk, cond
+
+
+def _unet_tokens(unet, x, timestep, encoder_hidden_states, res_time_embedding, unet_block_indices,
+                 unet_block_indices_type):
+    timestep, ctx, Lk, cond = _unet_inputs(x, timestep, encoder_hidden_states, res_time_embedding)
     return unet(x, timestep, ctx, Lk, cond_emb=cond, unet_block_indices=tuple(unet_block_indices),
                 unet_block_indices_type=unet_block_indices_type)
 
@@ -384,14 +391,20 @@ class LdmRocm(nn.Module):
             forward_unet = self.ema_unet
         else:
             forward_unet = self.unet
-        sample, unet_taps = _unet_tokens(forward_unet, Tok(noisy, B, h, w), timesteps, text_prompt,
-                                         res_time_embedding, self.unet_block_indices, self.unet_block_indices_type)
         if kwargs.pop("_keep_for_grad", False):
+            # training: the same forward, run block by block with the block inputs kept for backward.unet_backward_from_state
             if self.unet_block_indices_type != "after":
                 raise NotImplementedError("autograd through 'in'-type taps")
-            self._grad_keep = {"unet": forward_unet, "noisy": noisy, "B": B, "h": h, "w": w, "timesteps": timesteps,
-                               "indices": tuple(self.unet_block_indices), "taps": [t_.C for t_ in unet_taps],
+            from . import backward as bw
+            x_tok = Tok(noisy, B, h, w)
+            ts_, ctx_, Lk_, cond_ = _unet_inputs(x_tok, timesteps, text_prompt, res_time_embedding)
+            sample, unet_taps, state = bw.unet_forward_recorded(forward_unet, x_tok, ts_, ctx_, Lk_,
+                                                                tuple(self.unet_block_indices), cond_emb=cond_)
+            self._grad_keep = {"unet": forward_unet, "state": state, "B": B, "taps": [t_.C for t_ in unet_taps],
                                "n_enc": len(enc_taps), "dtype": dtype}
+        else:
+            sample, unet_taps = _unet_tokens(forward_unet, Tok(noisy, B, h, w), timesteps, text_prompt,
+                                             res_time_embedding, self.unet_block_indices, self.unet_block_indices_type)
 
         # feature lists as channels-last Toks; converted to NCHW f32 at the API boundary unless the (HIP) backbone
         # asked for tokens (madm_amd.backbone passes _return_tokens=True)
@@ -456,12 +469,11 @@ class _UNetTapsFn(torch.autograd.Function):
     def backward(ctx, *gouts):
         from . import backward as bw
         k = ctx.keep
-        unet, dtype, B, h, w = k["unet"], k["dtype"], k["B"], k["h"], k["w"]
+        unet, dtype, B = k["unet"], k["dtype"], k["B"]
         saved = ctx.saved_tensors
         cond_inputs = saved[0]
         cond_emb = saved[1] if len(saved) > 1 else None
         n_taps = len(k["taps"])
-        kt = ops.k_tile(dtype)
 
         def tokens(g, cpad=None):   # NCHW f32 gradient -> channels-last tokens of the compute dtype
             return ops.nchw_to_nhwc(g.float().contiguous(), dtype, cpad if cpad is not None else g.shape[1])
@@ -470,18 +482,9 @@ class _UNetTapsFn(torch.autograd.Function):
         dsample = None
         if k["with_sample"] and gouts[n_taps] is not None:
             dsample = tokens(gouts[n_taps], cpad=unet.conv_out.n_pad)
-        Lk = cond_inputs.shape[1]
-        ctx_tok = ops.cast_from_f32(cond_inputs.detach().float().contiguous().view(B * Lk, cond_inputs.shape[2]), dtype)
-        cond = None
-        if cond_emb is not None:
-            cond = cond_emb.detach()
-            if cond.dim() == 3 and cond.shape[1] == 1:
-                cond = cond[:, 0]
-            cond = cond.float().contiguous()
         names = k["param_names"]
         base = any(".lora_" not in n for n in names)
-        res = bw.unet_backward(unet, Tok(k["noisy"], B, h, w), k["timesteps"], ctx_tok, Lk, dtaps, k["indices"],
-                               cond_emb=cond, dsample=dsample, base_grads=base)
+        res = bw.unet_backward_from_state(k.pop("state"), dtaps, dsample=dsample, base_grads=base)
         g_ctx = None
         if cond_inputs.requires_grad:
             g_ctx = ops.rows_to_f32(res["ctx"])[:, :cond_inputs.shape[2]].reshape(cond_inputs.shape).to(cond_inputs.dtype)
