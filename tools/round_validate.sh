@@ -9,6 +9,8 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "sm
 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/rc.txt; cut -c1-900 $O/bench.json
 python bench.py --workload eval --steps 10 --warmup 2 > $O/bench_eval.json 2> $O/bench_eval.err; cut -c1-300 $O/bench_eval.json
 python tools/bench_optim.py > $O/optim.txt 2>&1; cat $O/optim.txt
+python tools/bench_backward.py > $O/backward_blocks.txt 2>&1; tail -14 $O/backward_blocks.txt
+python tools/bench_unet_backward.py > $O/unet_backward.txt 2>&1; tail -4 $O/unet_backward.txt
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-profile --streams 1 > $O/stats.log 2>&1)
 python tools/kstats.py $O/stats 25 > $O/kernel_stats.txt 2>&1; head -12 $O/kernel_stats.txt; python tools/last_replay.py $O/stats > $O/last_replay.txt; head -30 $O/last_replay.txt
 bash tools/pmc.sh $tag/pmc $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-graph
