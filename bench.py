@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2, help="images per GPU (BASELINE: 2)")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--graphs", type=int, default=1,
                     help="graph executables replayed round-robin (measured: 1, 2 and 3 give the same step time, the "
@@ -184,7 +184,7 @@ def main():
     dist = mdist.init("nccl", device)   # RCCL: barrier + max-over-ranks only, no data-path collective
 
     from madm_amd.ldm_rocm import LdmRocm
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     if args.workload == "eval":
         args.batch = 1
         model = build_eval_model(dtype, device)
@@ -303,7 +303,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
     if rank == 0:
         images = args.batch * world * args.steps
         value = images / elapsed
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "f16") else PEAK_F32_TFLOPS
         alg = ALG_FLOP_PER_IMAGE if args.workload == "extract" else 6.34725e12   # full eval forward
         out = {
             "metric": "UNet feature-extract images/sec @512x512 bs=2/GPU" if args.workload == "extract"

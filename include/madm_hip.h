@@ -15,6 +15,9 @@
  *   - `dtype` selects the storage/MFMA type of activations and weights:
  *       MADM_F32  -> f32 storage, v_mfma_f32_16x16x4_f32   (exact-f32 parity mode)
  *       MADM_BF16 -> bf16 storage, v_mfma_f32_16x16x32_bf16 (fast mode); f32 accumulate;
+ *       MADM_F16  -> fp16 storage, v_mfma_f32_16x16x32_f16 (same rate and kernels as bf16, 3 more mantissa
+ *                    bits: the reference's own autocast arithmetic, engine/train_loop.py:277,
+ *                    evaluation/evaluator.py:62-66); f32 accumulate;
  *     bias / time rows / norm parameters / statistics are always f32 (f64 for GN sums);
  *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous on it,
  *     capture-safe (no allocation, no synchronisation), re-entrant across streams;
@@ -40,7 +43,7 @@ typedef enum {
     MADM_ERR_LAUNCH = -3
 } madm_status;
 
-typedef enum { MADM_F32 = 0, MADM_BF16 = 1 } madm_dtype;
+typedef enum { MADM_F32 = 0, MADM_BF16 = 1, MADM_F16 = 2 } madm_dtype;
 
 /* activation codes of the norm / conv-input fusions */
 typedef enum { MADM_ACT_NONE = 0, MADM_ACT_SILU = 1, MADM_ACT_RELU = 2 } madm_act;

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("MADM_HIP_LIB") or os.path.join(_HERE, "libmadm_hip.so
 
 MADM_F32 = 0
 MADM_BF16 = 1
+MADM_F16 = 2
 EPI_NONE = 0
 EPI_GEGLU = 1
 EPI_RELU = 2

@@ -264,11 +264,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
             const int tq = fi >> 2, tp = fi & 3;
 #pragma unroll
             for (int u = 0; u < NS / 2; ++u) {
-                bf16x8 pf;
+                typename TT<T>::vec8 pf;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pf[r] = (bf16_t)s[2 * u][r];
-                    pf[4 + r] = (bf16_t)s[2 * u + 1][r];
+                    pf[r] = (T)s[2 * u][r];
+                    pf[4 + r] = (T)s[2 * u + 1][r];
                 }
                 const uint4 pfu = __builtin_bit_cast(uint4, pf);
                 const char* va = Vs + ((2 * u) * 16 + fg * 4 + tq) * C::V_ROWB + tp * 8;
@@ -367,8 +367,8 @@ extern "C" int madm_debug_read_attn_stamps(unsigned long long* host, int n) {
 extern "C" int madm_attention_fwd(const madm_attention_args* a, void* stream) {
     MADM_REQUIRE(a && a->q && a->k && a->v && a->o, "attention: null pointer");
     MADM_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->D > 0, "attention: bad dims");
-    const int es = a->dtype == MADM_BF16 ? 2 : 4;
-    MADM_REQUIRE(a->dtype == MADM_F32 || a->dtype == MADM_BF16, "attention: bad dtype");
+    const int es = madm_esize(a->dtype);
+    MADM_REQUIRE(madm_dtype_ok(a->dtype), "attention: bad dtype");
     MADM_REQUIRE((a->D * es) % 16 == 0, "attention: head dim %d not 16-byte granular", a->D);
     MADM_REQUIRE((a->ldq * es) % 16 == 0 && (a->ldk * es) % 16 == 0 && (a->ldv * es) % 16 == 0 &&
                      (a->ldo * es) % 8 == 0,
@@ -393,6 +393,15 @@ extern "C" int madm_attention_fwd(const madm_attention_args* a, void* stream) {
             case 80: return a->Lk >= 512 ? launch_attn<bf16_t, 3, 5, 4, 8>(p, s) : launch_attn<bf16_t, 3, 5, 4, 4>(p, s);
             case 160: return launch_attn<bf16_t, 5, 10, 4, 4>(p, s);
             case 512: return launch_attn<bf16_t, 16, 32, 2, 2>(p, s);
+            default: break;
+        }
+    } else if (a->dtype == MADM_F16) {
+        switch (a->D) {
+            case 40: return a->Lk >= 512 ? launch_attn<f16_t, 2, 3, 4, 8>(p, s) : launch_attn<f16_t, 2, 3, 4, 4>(p, s);
+            case 64: return launch_attn<f16_t, 2, 4, 4, 4>(p, s);
+            case 80: return a->Lk >= 512 ? launch_attn<f16_t, 3, 5, 4, 8>(p, s) : launch_attn<f16_t, 3, 5, 4, 4>(p, s);
+            case 160: return launch_attn<f16_t, 5, 10, 4, 4>(p, s);
+            case 512: return launch_attn<f16_t, 16, 32, 2, 2>(p, s);
             default: break;
         }
     } else {

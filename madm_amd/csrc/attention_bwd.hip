@@ -112,11 +112,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnBwdP p) {
             const int tq = fi >> 2, tp = fi & 3;
 #pragma unroll
             for (int u = 0; u < NS / 2; ++u) {
-                bf16x8 pf;
+                typename TT<T>::vec8 pf;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    pf[r] = (bf16_t)w[2 * u][r];
-                    pf[4 + r] = (bf16_t)w[2 * u + 1][r];
+                    pf[r] = (T)w[2 * u][r];
+                    pf[4 + r] = (T)w[2 * u + 1][r];
                 }
                 const uint4 pfu = __builtin_bit_cast(uint4, pf);
                 const char* va = As + ((2 * u) * 16 + fg * 4 + tq) * ROWB + tp * 8;
@@ -307,8 +307,8 @@ extern "C" size_t madm_attention_bwd_workspace_bytes(const madm_attention_bwd_ar
 extern "C" int madm_attention_bwd(const madm_attention_bwd_args* a, void* stream) {
     MADM_REQUIRE(a && a->q && a->k && a->v && a->o && a->dout && a->dq && a->dk && a->dv, "attention_bwd: null pointer");
     MADM_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->D > 0, "attention_bwd: bad dims");
-    MADM_REQUIRE(a->dtype == MADM_F32 || a->dtype == MADM_BF16, "attention_bwd: bad dtype");
-    const int es = a->dtype == MADM_BF16 ? 2 : 4;
+    MADM_REQUIRE(madm_dtype_ok(a->dtype), "attention_bwd: bad dtype");
+    const int es = madm_esize(a->dtype);
     MADM_REQUIRE((a->D * es) % 16 == 0, "attention_bwd: head dim %d not 16-byte granular", a->D);
     MADM_REQUIRE((a->ldq * es) % 16 == 0 && (a->ldk * es) % 16 == 0 && (a->ldv * es) % 16 == 0 &&
                      (a->ldo * es) % 16 == 0 && (a->lddo * es) % 16 == 0 && (a->lddq * es) % 8 == 0 &&
@@ -334,6 +334,14 @@ extern "C" int madm_attention_bwd(const madm_attention_bwd_args* a, void* stream
             case 64: return launch_attn_bwd<bf16_t, 2, 4>(p, s);
             case 80: return launch_attn_bwd<bf16_t, 3, 5>(p, s);
             case 160: return launch_attn_bwd<bf16_t, 5, 10>(p, s);
+            default: break;
+        }
+    } else if (a->dtype == MADM_F16) {
+        switch (a->D) {
+            case 40: return launch_attn_bwd<f16_t, 2, 3>(p, s);
+            case 64: return launch_attn_bwd<f16_t, 2, 4>(p, s);
+            case 80: return launch_attn_bwd<f16_t, 3, 5>(p, s);
+            case 160: return launch_attn_bwd<f16_t, 5, 10>(p, s);
             default: break;
         }
     } else {

@@ -7,7 +7,15 @@
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// elements per 16-byte chunk / bytes per element of a madm_dtype (host side)
+static inline int madm_epc(int dtype) { return dtype == MADM_F32 ? 4 : 8; }
+static inline int madm_esize(int dtype) { return dtype == MADM_F32 ? 4 : 2; }
+static inline bool madm_dtype_ok(int dtype) { return dtype == MADM_F32 || dtype == MADM_BF16 || dtype == MADM_F16; }
 
 void madm_set_error(const char* fmt, ...);
 int madm_check_launch(const char* what);
@@ -29,8 +37,15 @@ template <> struct TT<float> {
 };
 template <> struct TT<bf16_t> {
     static constexpr int EPC = 8;
+    typedef bf16x8 vec8;
     static __device__ __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
     static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+template <> struct TT<f16_t> {
+    static constexpr int EPC = 8;
+    typedef f16x8 vec8;
+    static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
 };
 
 // unpack a 16-byte chunk into floats / pack floats into a chunk
@@ -41,6 +56,11 @@ template <> __device__ __forceinline__ void chunk_to_f32<float>(const uint4& c, 
 }
 template <> __device__ __forceinline__ void chunk_to_f32<bf16_t>(const uint4& c, float* f) {
     bf16x8 v = __builtin_bit_cast(bf16x8, c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <> __device__ __forceinline__ void chunk_to_f32<f16_t>(const uint4& c, float* f) {
+    f16x8 v = __builtin_bit_cast(f16x8, c);
 #pragma unroll
     for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
 }
@@ -55,6 +75,12 @@ template <> __device__ __forceinline__ uint4 f32_to_chunk<bf16_t>(const float* f
     for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
     return __builtin_bit_cast(uint4, v);
 }
+template <> __device__ __forceinline__ uint4 f32_to_chunk<f16_t>(const float* f) {
+    f16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (f16_t)f[i];
+    return __builtin_bit_cast(uint4, v);
+}
 
 // store 4 consecutive elements converted from f32 (8 B for bf16, 16 B for f32)
 template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
@@ -66,6 +92,11 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
     o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
     *reinterpret_cast<bf16x4*>(p) = o;
 }
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, f32x4 v) {
+    f16x4 o;
+    o[0] = (f16_t)v[0]; o[1] = (f16_t)v[1]; o[2] = (f16_t)v[2]; o[3] = (f16_t)v[3];
+    *reinterpret_cast<f16x4*>(p) = o;
+}
 template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
 template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) {
     float4 v = *reinterpret_cast<const float4*>(p);
@@ -73,6 +104,10 @@ template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) {
 }
 template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
     bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <> __device__ __forceinline__ f32x4 load4<f16_t>(const f16_t* p) {
+    f16x4 v = *reinterpret_cast<const f16x4*>(p);
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 template <typename T> __device__ __forceinline__ void store2(T* p, float a, float b);
@@ -85,10 +120,16 @@ template <> __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, f
     o[0] = (bf16_t)a; o[1] = (bf16_t)b;
     *reinterpret_cast<bf16x2*>(p) = o;
 }
+template <> __device__ __forceinline__ void store2<f16_t>(f16_t* p, float a, float b) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    f16x2 o;
+    o[0] = (f16_t)a; o[1] = (f16_t)b;
+    *reinterpret_cast<f16x2*>(p) = o;
+}
 
 // ---- one 16-byte operand chunk per lane -> MFMA ----------------------------------------
 // Both operands are read as "row (lane & 15), 16-byte chunk (lane >> 4)" of a [rows][K] tile.
-// bf16: one v_mfma_f32_16x16x32_bf16 (lane group g holds k = 8g .. 8g+7).
+// bf16 / f16: one v_mfma_f32_16x16x32_bf16 / _f16 (lane group g holds k = 8g .. 8g+7).
 // f32 : four v_mfma_f32_16x16x4_f32, element s of every lane's float4 at step s -- a
 //       permutation of k that is the same for both operands, so the sum is unchanged.
 // D[i][j] = sum_k a(row i, k) * b(row j, k); lane holds j = lane & 15, i = 4*(lane>>4) + reg.
@@ -98,6 +139,11 @@ template <>
 __device__ __forceinline__ void mma16<bf16_t>(const uint4& a, const uint4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma16<f16_t>(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                               __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 template <>
 __device__ __forceinline__ void mma16<float>(const uint4& a, const uint4& b, f32x4& c) {
@@ -145,6 +191,9 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
             __VA_ARGS__;                                         \
         } else if ((dtype) == MADM_BF16) {                       \
             typedef bf16_t T;                                    \
+            __VA_ARGS__;                                         \
+        } else if ((dtype) == MADM_F16) {                        \
+            typedef f16_t T;                                     \
             __VA_ARGS__;                                         \
         } else {                                                 \
             madm_set_error("unknown dtype %d", (int)(dtype));    \

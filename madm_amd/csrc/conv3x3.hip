@@ -289,3 +289,4 @@ extern "C" int madm_debug_read_c3_stamps(unsigned long long* host, int n) {
 #endif
 template int launch_conv3x3_halo<float>(const IgemmP&, int, hipStream_t);
 template int launch_conv3x3_halo<bf16_t>(const IgemmP&, int, hipStream_t);
+template int launch_conv3x3_halo<f16_t>(const IgemmP&, int, hipStream_t);

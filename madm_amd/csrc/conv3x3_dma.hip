@@ -277,3 +277,4 @@ int launch_conv3x3_halo_dma(const IgemmP& p, int bn, hipStream_t s) {
 }
 template int launch_conv3x3_halo_dma<float>(const IgemmP&, int, hipStream_t);
 template int launch_conv3x3_halo_dma<bf16_t>(const IgemmP&, int, hipStream_t);
+template int launch_conv3x3_halo_dma<f16_t>(const IgemmP&, int, hipStream_t);

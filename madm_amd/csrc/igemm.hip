@@ -569,6 +569,7 @@ const Tuned g_tuned[] = {
     {-1, 0, 0, 0, 0, 0, 0, 0}};
 
 const Tuned* find_tuned(int dtype, int M, int N, int K, int KH, int variant) {
+    if (dtype == MADM_F16) dtype = MADM_BF16;   // same kernels, same instruction rate: the bf16 table serves both
     if (g_tile_override != 0) return nullptr;
     for (const Tuned* t = g_tuned; t->dtype >= 0; ++t)
         if (t->dtype == dtype && t->M == M && t->N == N && t->K == K && t->KH == KH && t->variant == variant) return t;
@@ -625,8 +626,8 @@ void tile_dims(int t, int& bm, int& bn) {
 
 int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     MADM_REQUIRE(a != nullptr, "conv2d: null args");
-    MADM_REQUIRE(a->dtype == MADM_F32 || a->dtype == MADM_BF16, "conv2d: bad dtype %d", a->dtype);
-    const int bke = (a->dtype == MADM_BF16) ? 64 : 32;
+    MADM_REQUIRE(madm_dtype_ok(a->dtype), "conv2d: bad dtype %d", a->dtype);
+    const int bke = (8 * madm_epc(a->dtype));
     MADM_REQUIRE(a->in1 && a->w && a->out, "conv2d: null tensor pointer");
     MADM_REQUIRE(a->C1 > 0 && a->C1 % bke == 0, "conv2d: C1=%d must be a positive multiple of %d", a->C1, bke);
     MADM_REQUIRE(a->C2 >= 0 && a->C2 % bke == 0, "conv2d: C2=%d must be a multiple of %d", a->C2, bke);
@@ -662,7 +663,7 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     MADM_REQUIRE(p.ld1 >= a->C1 && p.ld2 >= a->C2 && p.ld1 % (bke / 8) == 0 && p.ld2 % (bke / 8) == 0,
                  "conv2d: bad source row strides ld1=%d ld2=%d", p.ld1, p.ld2);
     {
-        const size_t es = (a->dtype == MADM_BF16) ? 2 : 4;
+        const size_t es = madm_esize(a->dtype);
         const size_t px = (size_t)a->B * a->IH * a->IW;
         const size_t b1 = ((px - 1) * p.ld1 + a->C1) * es;
         const size_t b2 = a->C2 ? ((px - 1) * p.ld2 + a->C2) * es : 0;
@@ -767,7 +768,7 @@ int madm_conv2d_pick_tile(const madm_conv2d_args* a) {
 
 int madm_conv2d_suggest_splitk(const madm_conv2d_args* a) {
     if (!a) return 1;
-    const int bke = (a->dtype == MADM_BF16) ? 64 : 32;
+    const int bke = (8 * madm_epc(a->dtype));
     const int M = a->B * a->OH * a->OW;
     const int Ktot = a->KH * a->KW * (a->C1 + a->C2);
     const int nk = Ktot / bke;
@@ -813,11 +814,12 @@ int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream) {
         p.gn_G = a->gn_groups; p.gn_eps = a->gn_eps; p.gn_magic = magic; p.act = a->gn_act;
     }
     if (is_halo_tile(t)) {   // the halo kernel splits K by whole channel chunks
-        const int nchunks = p.Ctot / ((a->dtype == MADM_BF16) ? 64 : 32);
+        const int nchunks = p.Ctot / ((8 * madm_epc(a->dtype)));
         if (p.splitk > nchunks) p.splitk = nchunks;
     }
     hipStream_t s = (hipStream_t)stream;
     if (a->dtype == MADM_F32) return launch<float>(p, t, s);
+    if (a->dtype == MADM_F16) return launch<f16_t>(p, t, s);
     return launch<bf16_t>(p, t, s);
 }
 

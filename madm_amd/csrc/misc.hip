@@ -258,7 +258,7 @@ extern "C" {
 int madm_image_to_nhwc(int dtype, const float* img, void* out, int B, int C, int H, int W, int Cpad, float mean,
                        float std, float* minmax, void* stream) {
     MADM_REQUIRE(img && out, "image_to_nhwc: null pointer");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % epc == 0,
                  "image_to_nhwc: bad dims (C=%d Cpad=%d)", C, Cpad);
     MADM_REQUIRE(std != 0.f, "image_to_nhwc: std == 0");
@@ -273,7 +273,7 @@ int madm_image_to_nhwc(int dtype, const float* img, void* out, int B, int C, int
 int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H, int W, int Kpad, float mean,
                             float std, float* minmax, void* stream) {
     MADM_REQUIRE(img && out, "image_to_im2col3x3: null pointer");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(B > 0 && H > 0 && W > 0 && Kpad >= 27 && Kpad % epc == 0, "image_to_im2col3x3: bad dims");
     MADM_REQUIRE(std != 0.f, "image_to_im2col3x3: std == 0");
     hipStream_t s = (hipStream_t)stream;
@@ -294,7 +294,7 @@ int madm_latents_add_noise(int dtype, const void* moments, int ldm, float scalin
                            const float* sqrt_ac, const float* sqrt_1mac, const int64_t* timesteps,
                            float* latents_nchw, void* noisy, int B, int HW, int Cpad, void* stream) {
     MADM_REQUIRE(moments && noise && sqrt_ac && sqrt_1mac && timesteps && noisy, "latents_add_noise: null pointer");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(B > 0 && HW > 0 && ldm >= 4 && Cpad >= 4 && Cpad % epc == 0, "latents_add_noise: bad dims");
     hipStream_t s = (hipStream_t)stream;
     MADM_DISPATCH_DTYPE(dtype, (latents_add_noise_kernel<T><<<grid_for((size_t)B * HW), 256, 0, s>>>(

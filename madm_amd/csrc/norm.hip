@@ -352,7 +352,7 @@ int madm_softmax_rows(int dtype, const float* s, void* p, int rows, int L, int l
 int madm_groupnorm_stats(int dtype, const void* x, int B, int HW, int C, double* chsums, void* stream) {
     MADM_REQUIRE(x && chsums, "groupnorm_stats: null pointer");
     MADM_REQUIRE(B > 0 && HW > 0 && C > 0, "groupnorm_stats: bad dims B=%d HW=%d C=%d", B, HW, C);
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(C % epc == 0, "groupnorm_stats: C=%d must be a multiple of %d", C, epc);
     MADM_REQUIRE((size_t)2 * C * sizeof(float) <= 64 * 1024, "groupnorm_stats: C=%d too large", C);
     // enough blocks to fill the chip, at least 64 rows each
@@ -376,7 +376,7 @@ int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int 
     MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && Ctot % G == 0 && c_off >= 0 && c_off + C <= Ctot && ldy >= c_off + C,
                  "groupnorm_apply: bad dims");
     MADM_REQUIRE(C1 > 0 && C1 <= Ctot && (C1 == Ctot || sums2), "groupnorm_apply: bad statistics sources (C1=%d Ctot=%d)", C1, Ctot);
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(C % epc == 0 && c_off % epc == 0 && ldy % epc == 0, "groupnorm_apply: C/c_off/ldy must be multiples of %d", epc);
     MADM_REQUIRE(act >= 0 && act <= 2 && (!residual || (ldres >= c_off + C && ldres % epc == 0)), "groupnorm_apply: bad act/residual");
     const size_t shm = ((size_t)2 * C + 2 * G) * sizeof(float);
@@ -409,7 +409,7 @@ int madm_layernorm_fwd(int dtype, const void* x, void* y, int M, int C, const fl
                        float eps, void* stream) {
     MADM_REQUIRE(x && y && gamma && beta, "layernorm: null pointer");
     MADM_REQUIRE(M > 0 && C > 0, "layernorm: bad dims");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(C % epc == 0, "layernorm: C=%d must be a multiple of %d", C, epc);
     MADM_REQUIRE(C / epc <= 64 * 5, "layernorm: C=%d too large (max %d)", C, 64 * 5 * epc);
     dim3 grid((unsigned)((M + 3) / 4));

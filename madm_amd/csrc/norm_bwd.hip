@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* __restrict__ pr
 int gn_bwd_check(int dtype, const void* x, const void* dy, int lddy, int B, int HW, int C, int c_off, int Ctot, int G,
                  const double* sums1, int C1, const double* sums2, const float* gamma, const float* beta,
                  const double* bsums, size_t lds_floats) {
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(x && dy && sums1 && gamma && beta && bsums, "groupnorm_bwd: null argument");
     MADM_REQUIRE(B > 0 && HW > 0 && C > 0 && C % epc == 0 && lddy % epc == 0 && c_off % epc == 0,
                  "groupnorm_bwd: C / lddy / c_off must be multiples of %d elements", epc);
@@ -399,7 +399,7 @@ int madm_groupnorm_bwd_apply(int dtype, const void* x, const void* dy, int lddy,
                                 (size_t)6 * C);
     if (rc != MADM_OK) return rc;
     MADM_REQUIRE(dx && (!dgamma == !dbeta), "groupnorm_bwd_apply: dx missing or only one of dgamma / dbeta given");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(!dres || lddres % epc == 0, "groupnorm_bwd_apply: lddres must be a multiple of %d elements", epc);
     const long long total = (long long)HW * (C / epc);
     int strips = (int)((total + 256 * 4 - 1) / (256 * 4));
@@ -417,7 +417,7 @@ int madm_groupnorm_bwd_apply(int dtype, const void* x, const void* dy, int lddy,
 
 int madm_geglu_bwd(int dtype, const void* pre, const void* dout, void* dpre, size_t M, int N2, void* stream) {
     MADM_REQUIRE(pre && dout && dpre && M > 0 && N2 > 0, "geglu_bwd: bad argument");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(N2 % epc == 0, "geglu_bwd: 2N = %d must be a multiple of %d", N2, epc);
     const size_t chunks = M * (size_t)(N2 / epc);
     size_t blocks = (chunks + 255) / 256;
@@ -431,7 +431,7 @@ int madm_layernorm_bwd(int dtype, const void* x, const void* dy, void* dx, int M
                        float* dgamma, float* dbeta, const void* dres, void* stream) {
     MADM_REQUIRE(x && dy && dx && gamma && M > 0 && C > 0, "layernorm_bwd: bad argument");
     MADM_REQUIRE(!dgamma == !dbeta, "layernorm_bwd: dgamma and dbeta go together");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(C % epc == 0, "layernorm_bwd: C=%d must be a multiple of %d", C, epc);
     MADM_REQUIRE(C / epc <= 64 * 5, "layernorm_bwd: C=%d too large (max %d)", C, 64 * 5 * epc);
     int blocks = (M + 3) / 4;

@@ -220,7 +220,7 @@ extern "C" {
 int madm_resize_bilinear(int dtype, const void* in, int ldi, void* out, int ldo, int B, int IH, int IW, int OH, int OW,
                          int C, void* stream) {
     MADM_REQUIRE(in && out && B > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0, "resize_bilinear: bad args");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(C % epc == 0 && ldi >= C && ldo >= C && ldi % epc == 0 && ldo % epc == 0, "resize_bilinear: C/ld must be multiples of %d", epc);
     const size_t total = (size_t)B * OH * OW * (C / epc);
     MADM_REQUIRE(total < 0x7fffffffull, "resize_bilinear: tensor too large for 32-bit indexing");
@@ -240,7 +240,7 @@ int madm_resize_bilinear_nchw_f32(const float* in, float* out, int planes, int I
 int madm_dwconv3x3(int dtype, const void* x, const float* w, const float* scale, const float* shift, void* y, int ldy,
                    int B, int H, int W, int C, int dilation, int act, void* stream) {
     MADM_REQUIRE(x && w && scale && shift && y && B > 0 && H > 0 && W > 0 && C > 0 && dilation > 0, "dwconv3x3: bad args");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(C % epc == 0 && ldy >= C && ldy % epc == 0 && act >= 0 && act <= 2, "dwconv3x3: bad C/ldy/act");
     const size_t total = (size_t)B * H * W * (C / epc);
     MADM_REQUIRE(total < 0x7fffffffull, "dwconv3x3: tensor too large for 32-bit indexing");
@@ -261,7 +261,7 @@ int madm_scale_pad_crop_nchw_f32(const float* in, float* out, int planes, int IH
 int madm_slide_merge(int dtype, const void* win, void* out, int nW, int B, int h, int w, int Wc, int C, const int* x1,
                      void* stream) {
     MADM_REQUIRE(win && out && x1 && nW >= 1 && nW <= 4 && B > 0 && h > 0 && w > 0 && Wc >= w && C > 0, "slide_merge: bad args");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(C % epc == 0, "slide_merge: C must be a multiple of %d", epc);
     const size_t total = (size_t)B * h * Wc * (C / epc);
     MADM_REQUIRE(total < 0x7fffffffull, "slide_merge: tensor too large for 32-bit indexing");

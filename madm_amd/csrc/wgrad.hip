@@ -358,8 +358,8 @@ unsigned bwd_grid_for(size_t n) {
 extern "C" int madm_zero_insert2x(int dtype, const void* x, void* y, int B, int OH, int OW, int H, int W, int C,
                                   void* stream) {
     MADM_REQUIRE(x && y && B > 0 && OH > 0 && OW > 0 && H > 0 && W > 0 && C > 0, "zero_insert2x: bad argument");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
-    MADM_REQUIRE(dtype == MADM_F32 || dtype == MADM_BF16, "zero_insert2x: unknown dtype %d", dtype);
+    const int epc = madm_epc(dtype);
+    MADM_REQUIRE(madm_dtype_ok(dtype), "zero_insert2x: unknown dtype %d", dtype);
     MADM_REQUIRE(C % epc == 0, "zero_insert2x: C = %d must be a multiple of %d", C, epc);
     const size_t total = (size_t)B * H * W * (C / epc);
     zero_insert2x_kernel<float><<<bwd_grid_for(total), 256, 0, (hipStream_t)stream>>>((const uint4*)x, (uint4*)y, OH, OW, H,
@@ -369,7 +369,7 @@ extern "C" int madm_zero_insert2x(int dtype, const void* x, void* y, int B, int 
 
 extern "C" int madm_sumpool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream) {
     MADM_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "sumpool2x2: bad argument");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(C % epc == 0, "sumpool2x2: C = %d must be a multiple of %d", C, epc);
     const size_t total = (size_t)B * H * W * (C / epc);
     MADM_DISPATCH_DTYPE(dtype, (sumpool2x2_kernel<T><<<bwd_grid_for(total), 256, 0, (hipStream_t)stream>>>(
@@ -379,7 +379,7 @@ extern "C" int madm_sumpool2x2(int dtype, const void* x, void* y, int B, int H, 
 
 extern "C" int madm_colsum(int dtype, const void* x, int ldx, int B, int HW, int C, float* out, void* stream) {
     MADM_REQUIRE(x && out && B > 0 && HW > 0 && C > 0, "colsum: bad argument");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(C % epc == 0 && ldx % epc == 0 && ldx >= C, "colsum: C / ldx must be multiples of %d elements", epc);
     int slices = (HW + 31) / 32;
     if (slices > 512) slices = 512;
@@ -394,7 +394,7 @@ extern "C" int madm_colsum(int dtype, const void* x, int ldx, int B, int HW, int
 
 extern "C" int madm_add(int dtype, const void* a, const void* b, void* y, size_t n, void* stream) {
     MADM_REQUIRE(a && b && y && n > 0, "add: bad argument");
-    const int epc = dtype == MADM_BF16 ? 8 : 4;
+    const int epc = madm_epc(dtype);
     MADM_REQUIRE(n % epc == 0, "add: n must be a multiple of %d elements", epc);
     const size_t chunks = n / epc;
     MADM_DISPATCH_DTYPE(dtype, (add_kernel<T><<<bwd_grid_for(chunks), 256, 0, (hipStream_t)stream>>>(
@@ -411,9 +411,9 @@ extern "C" int madm_silu_bwd(int dtype, const void* x, const void* dy, void* dx,
 
 extern "C" int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream) {
     MADM_REQUIRE(a && a->in1 && a->dout && a->dw, "conv2d_wgrad: null argument");
-    MADM_REQUIRE(a->dtype == MADM_F32 || a->dtype == MADM_BF16, "conv2d_wgrad: unknown dtype %d", a->dtype);
-    const int epc = a->dtype == MADM_BF16 ? 8 : 4;
-    const size_t esz = a->dtype == MADM_BF16 ? 2 : 4;
+    MADM_REQUIRE(madm_dtype_ok(a->dtype), "conv2d_wgrad: unknown dtype %d", a->dtype);
+    const int epc = madm_epc(a->dtype);
+    const size_t esz = madm_esize(a->dtype);
     MADM_REQUIRE(a->C1 > 0 && a->C2 >= 0 && (a->C2 == 0 || a->in2), "conv2d_wgrad: bad channel split %d + %d", a->C1,
                  a->C2);
     MADM_REQUIRE(a->C1 % epc == 0 && a->C2 % epc == 0, "conv2d_wgrad: C1 / C2 must be multiples of %d elements", epc);
@@ -466,6 +466,7 @@ extern "C" int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream) 
     dim3 grid((unsigned)tilesN, (unsigned)tilesK, (unsigned)splitm);
     hipStream_t s = (hipStream_t)stream;
     if (a->dtype == MADM_BF16) conv2d_wgrad_kernel<bf16_t><<<grid, 256, 0, s>>>(p);
+    else if (a->dtype == MADM_F16) conv2d_wgrad_kernel<f16_t><<<grid, 256, 0, s>>>(p);
     else conv2d_wgrad_kernel<float><<<grid, 256, 0, s>>>(p);
     return madm_check_launch("conv2d_wgrad_kernel");
 }

@@ -9,22 +9,23 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (lib, check, Conv2dArgs, AttentionArgs, EPI_NONE, EPI_GEGLU, EPI_RELU, MADM_F32, MADM_BF16,
+from ._lib import (lib, check, Conv2dArgs, AttentionArgs, EPI_NONE, EPI_GEGLU, EPI_RELU, MADM_F32, MADM_BF16, MADM_F16,
                    ACT_NONE, ACT_SILU, ACT_RELU)
 
-_DT = {torch.float32: MADM_F32, torch.bfloat16: MADM_BF16}
+_DT = {torch.float32: MADM_F32, torch.bfloat16: MADM_BF16, torch.float16: MADM_F16}
+_SUFFIX = {torch.float32: "_f32", torch.bfloat16: "_bf16", torch.float16: "_f16"}
 
 
 def dtype_code(t):
     try:
         return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
     except KeyError:
-        raise TypeError(f"madm_amd supports float32 and bfloat16 tensors, got {t}")
+        raise TypeError(f"madm_amd supports float32, bfloat16 and float16 tensors, got {t}")
 
 
 def k_tile(dtype):
     """K-tile of the MFMA kernels in elements: channel counts must be multiples of it."""
-    return 64 if dtype == torch.bfloat16 else 32
+    return 32 if dtype == torch.float32 else 64
 
 
 def _stream():
@@ -188,7 +189,7 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     else:
         an, ak = alg_nk if alg_nk is not None else (N, KH * KW * (C1 + C2))
-        name = _TILE_NAMES[lib.madm_conv2d_pick_tile(ctypes.byref(a))] + ("_f32" if x1.dtype == torch.float32 else "_bf16")
+        name = _TILE_NAMES[lib.madm_conv2d_pick_tile(ctypes.byref(a))] + _SUFFIX[x1.dtype]
         desc = (f"M{M} N{N} K{KH * KW * (C1 + C2)} k{KH} s{stride}{' up' if upsample else ''}"
                 f"{' gn' if gn is not None else ''} sk{a.splitk}")
         es = x1.element_size()
@@ -248,7 +249,7 @@ def conv2d_wgrad(x1, dout, B, IH, IW, *, x2=None, KH=1, KW=1, stride=1, pad_t=0,
     else:
         es = x1.element_size()
         nbytes = B * IH * IW * (C1 + C2) * es + dout.numel() * es + dw.numel() * 4
-        with _Prof("conv2d_wgrad" + ("_f32" if x1.dtype == torch.float32 else "_bf16"), 2.0 * dout.shape[0] * N * K,
+        with _Prof("conv2d_wgrad" + _SUFFIX[x1.dtype], 2.0 * dout.shape[0] * N * K,
                    f"M{dout.shape[0]} N{N} K{K} k{KH} s{stride}", nbytes):
             check(lib.madm_conv2d_wgrad(ctypes.byref(a), _stream()), "madm_conv2d_wgrad")
     return dw
@@ -514,7 +515,7 @@ def attention(q, k, v, B, H, Lq, Lk, D, scale, out=None):
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.B, a.H, a.Lq, a.Lk, a.D = B, H, Lq, Lk, D
     a.scale = float(scale)
-    with _Prof(f"attn_d{D}" + ("_f32" if q.dtype == torch.float32 else "_bf16"), 4.0 * B * H * Lq * Lk * D,
+    with _Prof(f"attn_d{D}" + _SUFFIX[q.dtype], 4.0 * B * H * Lq * Lk * D,
                f"B{B} H{H} Lq{Lq} Lk{Lk}"):
         check(lib.madm_attention_fwd(ctypes.byref(a), _stream()), "madm_attention_fwd")
     return out
@@ -546,7 +547,7 @@ def attention_backward(q, k, v, o, dout, B, H, Lq, Lk, D, scale, outs=None):
     nbytes = lib.madm_attention_bwd_workspace_bytes(ctypes.byref(a))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
-    with _Prof(f"attn_bwd_d{D}" + ("_f32" if q.dtype == torch.float32 else "_bf16"), 14.0 * B * H * Lq * Lk * D,
+    with _Prof(f"attn_bwd_d{D}" + _SUFFIX[q.dtype], 14.0 * B * H * Lq * Lk * D,
                f"B{B} H{H} Lq{Lq} Lk{Lk}"):
         check(lib.madm_attention_bwd(ctypes.byref(a), _stream()), "madm_attention_bwd")
     return dq, dk, dv

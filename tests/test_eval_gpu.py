@@ -140,7 +140,7 @@ def _build_product(cfg_name, dtype):
 
 
 @pytest.mark.parametrize("name", ["eval_s345", "eval_depth"])
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES + [torch.float16], ids=["f32", "bf16", "f16"])
 def test_eval_forward_golden(cuda, name, dtype):
     """MTMADISE eval forward (mtmadise.py:657-691) end to end vs the vectors of the reference's own classes."""
     from madm_amd.meta_arch import MadmInference
@@ -165,6 +165,8 @@ def test_eval_forward_golden(cuda, name, dtype):
         decided = margin > 1e-3 * scale                       # pixels whose top-2 logits are not within fp32 noise
         assert torch.equal(labels[decided], gl[decided]), "labels differ where the reference margin is decisive"
         assert agree > 0.9999
+    elif dtype == torch.float16:
+        assert l2 < 2e-2 and agree > 0.995
     else:
         assert l2 < 8e-2 and agree > 0.97
     feats = model.backbone(model_input(model, img), input_modal='others')['output_features']
@@ -174,7 +176,7 @@ def test_eval_forward_golden(cuda, name, dtype):
         assert tuple(f.shape) == tuple(gold["feat_" + k + "_shape"].tolist())
         st = max(1, f.shape[-1] // 32)
         ef, lf = rel_err(f[:, ::8, ::st, ::st], g)
-        assert (ef < 1e-3) if dtype == torch.float32 else (lf < 8e-2), (k, ef, lf)
+        assert (ef < 1e-3) if dtype == torch.float32 else (lf < (2e-2 if dtype == torch.float16 else 8e-2)), (k, ef, lf)
 
 
 def model_input(model, img):

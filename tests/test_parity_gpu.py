@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 F32_TOL = 1e-3
 BF16_L2_TOL = 4e-2
+F16_L2_TOL = 8e-3     # fp16 storage (10 mantissa bits): the reference's own autocast arithmetic (engine/train_loop.py:277)
 
 
 class _LoraConfig:
@@ -54,18 +55,18 @@ def _compare(name, got, gold, dtype):
     for key, a, b in pairs:
         e, l2 = rel_err(a, b)
         report.append(f"{key}: max {e:.2e} l2 {l2:.2e}")
-        ok &= (e < F32_TOL) if dtype == torch.float32 else (l2 < BF16_L2_TOL)
+        ok &= (e < F32_TOL) if dtype == torch.float32 else (l2 < (F16_L2_TOL if dtype == torch.float16 else BF16_L2_TOL))
     print(name, dtype, "; ".join(report))
     assert ok, f"{name} {dtype}: " + "; ".join(report)
 
 
 @pytest.mark.parametrize("name", ["small_t0", "small_t60", "rect_t0", "full_t0"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_golden(extractor, name, dtype):
     _compare(name, _run(extractor, CASES[name], dtype), load_golden(name), dtype)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 def test_golden_lora(cuda, dtype):
     """peft-style LoRA (mtmadise.py:115-147): two adapters registered, 'Depth' active."""
     from madm_amd.ldm_rocm import LdmRocm
