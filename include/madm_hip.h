@@ -429,6 +429,57 @@ int madm_label_presence(const int64_t* label, size_t n, unsigned* presence256, v
 int madm_class_mix(const int64_t* label0, const int64_t* label1, const unsigned char* chosen256, const float* img0,
                    const float* img1, int C, int HW, float* mask_out, float* img_out, int64_t* label_out, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Training step of the meta-architecture (BASELINE config 4): what torch autograd does
+ * behind ``losses.backward()`` (engine/train_loop.py:203-217) for the train-mode DAFormer head
+ * (modeling/sem_seg_head/daformer_head.py:677-749), the CmdiseCriterion losses (modeling/criterion.py:120-131,155-254) and
+ * the prompt / time gates (modeling/meta_arch/ldm_base.py:675-712).  Train-mode BatchNorm needs no entry point of its
+ * own: over channels-last tokens it IS madm_groupnorm_* with B = 1, HW = all rows of the batch, G = C (per-channel
+ * statistics over batch and pixels, biased variance) -- forward, fused activation and backward included.
+ * ------------------------------------------------------------------------------- */
+/* y[b][p][c] = x[b][p][c] * scale[b][c] (f32 [B][C]): nn.Dropout2d(0.1) with scale = keep / (1 - p) per (image, channel)
+ * (daformer_head.py:677-699 cls_seg); the same call on the gradient is its backward.  x / y row strides ldx / ldy. */
+int madm_scale_channels(int dtype, const void* x, int ldx, const float* scale, void* y, int ldy, int B, int HW, int C,
+                        void* stream);
+/* train-mode nn.BatchNorm2d bookkeeping (mmcv ConvModule norm, daformer_head.py:364-372,455-461): folds the per-image
+ * channel sums chsums [B][C][2] (a conv epilogue's / madm_groupnorm_stats') into the batch sums st [1][C][2] that
+ * madm_groupnorm_* consume with B = 1, G = C, and updates running_mean / running_var (f32 [C], NULL = skip) with
+ * momentum and the unbiased variance over `count` = B * H * W elements. */
+int madm_bn_fold_stats(const double* chsums, int B, int C, double count, float momentum, double* st, float* running_mean,
+                       float* running_var, void* stream);
+/* dx = dy where y > 0 else 0, y = the ReLU's output (d2 BottleneckBlock's relu(GN(conv3) + shortcut),
+ * modeling/backbone/feature_extractor.py:347-359); n elements, dense. */
+int madm_relu_bwd(int dtype, const void* y, const void* dy, void* dx, size_t n, void* stream);
+/* weight gradient of madm_dwconv3x3 (before its affine / activation): dw (f32 [9][C], accumulated into)
+ * [t][c] += sum_pixels dy[p][c] * x[p + offset_t][c]; x dense [B*H*W][C], dy row stride lddy.  The DATA gradient of the
+ * depthwise conv is madm_dwconv3x3 itself on dy with the taps reversed (symmetric dilation). */
+int madm_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, int lddy, float* dw, int B, int H, int W, int C,
+                         int dilation, void* stream);
+/* adjoint of madm_resize_bilinear: dout [B*OH*OW][lddo] (C channels) -> din [B*IH*IW][C] dense, as two 1-D passes with
+ * an f32 intermediate [B*OH*IW][C] in `workspace` (gather form: deterministic, no atomics). */
+size_t madm_resize_bilinear_bwd_workspace_bytes(int B, int IW, int OH, int C);
+int madm_resize_bilinear_bwd(int dtype, const void* dout, int lddo, void* din, int B, int IH, int IW, int OH, int OW, int C,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* CmdiseCriterion.cross_entropy (criterion.py:120-131): F.cross_entropy(reduction='none', ignore_index) * pixel_weight on
+ * f32 logit tokens [M][ldx] (K classes), labels i64 [M], weight f32 [M] or NULL:
+ *   *loss_sum (f64, caller-zeroed, NULL = skip) += sum_i w_i (logsumexp(x_i) - x_i[label_i]) over the non-ignored pixels;
+ *   dlogits (NULL = skip; `dtype` tokens [M][ldd], columns >= K zero) = coef * (*gscale, NULL = 1) * w_i *
+ *   (softmax(x_i) - onehot(label_i)); the caller folds the mean's 1 / M and the loss weight into coef, gscale is the
+ *   upstream gradient of the loss scalar (GradScaler scale included) read on the device. */
+int madm_softmax_ce(int dtype, const float* logits, int ldx, int K, const int64_t* labels, const float* weight,
+                    int ignore_index, size_t M, double* loss_sum, const float* gscale, float coef, void* dlogits, int ldd,
+                    void* stream);
+/* vae_decoder / mic / denoise losses (criterion.py:222-254): pred, gt NCHW f32 [B][C][h][w]; mask f32 [B][Hm][Wm] read
+ * through F.interpolate(mode='nearest') to (h, w) and broadcast over C (NULL = 1):
+ *   *loss_sum (f64) += sum |pred - gt| * mask (l2 = 0) or sum (pred - gt)^2 * mask (l2 = 1);
+ *   dpred (NULL = skip) = coef * (*gscale) * mask * sign(pred - gt)  (or 2 (pred - gt)). */
+int madm_masked_l1(const float* pred, const float* gt, const float* mask, int B, int C, int h, int w, int Hm, int Wm, int l2,
+                   double* loss_sum, const float* gscale, float coef, float* dpred, void* stream);
+/* backward of madm_tanh_gate for dout [repeat][n]: with g_i = sum_r dout[r][i], dx1 += tanh(a1) g, da1 += (1 - tanh^2(a1))
+ * x1 g and likewise for (a2, x2); every output is ACCUMULATED into and may be NULL. */
+int madm_tanh_gate_bwd(const float* a1, const float* x1, const float* a2, const float* x2, const float* dout, float* da1,
+                       float* dx1, float* da2, float* dx2, size_t n, int repeat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,6 +168,20 @@ SYMBOLS = [
     ("madm_layernorm_bwd", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
     ("madm_geglu_bwd", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    ("madm_scale_channels", c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    ("madm_bn_fold_stats", c_int, [c_void_p, c_int, c_int, ctypes.c_double, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ("madm_relu_bwd", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    ("madm_dwconv3x3_wgrad", c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_void_p]),
+    ("madm_resize_bilinear_bwd_workspace_bytes", c_size_t, [c_int, c_int, c_int, c_int]),
+    ("madm_resize_bilinear_bwd", c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_void_p, c_size_t, c_void_p]),
+    ("madm_softmax_ce", c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_void_p,
+                                c_float, c_void_p, c_int, c_void_p]),
+    ("madm_masked_l1", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                               c_void_p, c_float, c_void_p, c_void_p]),
+    ("madm_tanh_gate_bwd", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_size_t, c_int, c_void_p]),
 ]
 
 

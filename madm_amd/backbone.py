@@ -87,6 +87,33 @@ class ClipFeatureProject(nn.Module):
     def forward(self, uncond_prompt, prefix=None, repeat=1):
         return self.get_cond_prompt(uncond_prompt, prefix, repeat), self.get_cond_time(prefix, repeat)
 
+    def backward(self, uncond_prompt, dcond_inputs, dcond_emb, grads=None):
+        """Gradients of :meth:`forward`'s two outputs (f32 [B, 77, 768] / [B, 1280] or None) w.r.t. the learnable prompt /
+        time parameters, ACCUMULATED into ``grads`` {parameter name: f32 tensor} (created when None) -- the two gradient
+        passes of a training step share these parameters when ``same_cond_params`` (ldm_base.py:632-717)."""
+        grads = {} if grads is None else grads
+
+        def acc(name, like):
+            if name not in grads:
+                grads[name] = torch.zeros_like(like, dtype=torch.float32)
+            return grads[name]
+
+        if dcond_inputs is not None and self.learnable_cond_prompt:
+            d = dcond_inputs.float().contiguous()
+            if self.without_prompt_alpha:
+                ops.tanh_gate_backward(d, self.prompt_embed.detach(), dx1=acc("prompt_embed", self.prompt_embed))
+            else:
+                ops.tanh_gate_backward(d, uncond_prompt.contiguous(), self.alpha_uncond_prompt.detach(),
+                                       self.prompt_embed.detach(), self.alpha_cond_prompt.detach(),
+                                       da1=acc("alpha_uncond_prompt", self.alpha_uncond_prompt),
+                                       da2=acc("alpha_cond_prompt", self.alpha_cond_prompt),
+                                       dx2=acc("prompt_embed", self.prompt_embed))
+        if dcond_emb is not None and self.learnable_cond_time:
+            d = dcond_emb.float().contiguous()
+            ops.tanh_gate_backward(d, self.time_embed.detach().contiguous(), self.alpha_cond_time.detach().contiguous(),
+                                   da1=acc("alpha_cond_time", self.alpha_cond_time), dx1=acc("time_embed", self.time_embed))
+        return grads
+
 
 class BasePromptTimeGenerator(nn.Module):
     """ldm_base.py:720-968 with ``ldm_extractor`` given (the LazyConfig always passes one)."""
@@ -184,22 +211,68 @@ class BottleneckBlock(nn.Module):
         self.conv2 = _D2Conv(bottleneck_channels, bottleneck_channels, 3, padding=1)
         self.conv3 = _D2Conv(bottleneck_channels, out_channels, 1)
 
-    def forward(self, x):
+    def forward(self, x, tape=None):
+        """``tape`` (a list): receives the record :meth:`backward` needs -- the raw conv outputs with their channel sums;
+        the normalised / activated tensors are recomputed there."""
         kt = ops.k_tile(x.t.dtype)
         if x.C != self.in_channels:   # e.g. the 3-channel decoder image travelling in a 4-wide tensor
             assert x.C > self.in_channels
         xin = x
         if x.C % kt != 0:
             xin = Tok(widen_tokens(x.t, self.in_channels, (self.in_channels + kt - 1) // kt * kt), x.B, x.H, x.W)
-        h = self.conv1(xin)
-        h = self.conv2(h, norm=self.conv1.norm, act="relu")          # GN + ReLU folded into the 3x3 conv when it fits
-        h = self.conv2.norm(h, act="relu")
-        h = self.conv3(h)
+        h1 = self.conv1(xin)
+        h2 = self.conv2(h1, norm=self.conv1.norm, act="relu")        # GN + ReLU folded into the 3x3 conv when it fits
+        a2 = self.conv2.norm(h2, act="relu")
+        h3 = self.conv3(a2)
+        hs = None
         if self.shortcut is not None:
-            s = self.shortcut.norm(self.shortcut(xin))
+            hs = self.shortcut(xin)
+            s = self.shortcut.norm(hs)
         else:
             s = x
-        return self.conv3.norm(h, act="relu", residual=s)
+        out = self.conv3.norm(h3, act="relu", residual=s)
+        if tape is not None:
+            tape.append((self, xin, h1, h2, h3, hs, out))
+        return out
+
+    def backward(self, rec, dout, need_dx=True):
+        """Backward of the recorded forward for the output gradient ``dout`` [M, Cout]: returns (dx [M, Cin(padded)] or
+        None, {parameter name: f32 gradient}).  torch autograd through detectron2's BottleneckBlock in the reference
+        (feature_extractor.py:347-359,367-396)."""
+        from . import backward as bw
+        _, xin, h1, h2, h3, hs, out = rec
+        B, HW = xin.B, xin.HW
+        grads = {}
+
+        def gn_bwd(conv, h, dy, act, dres=None):
+            n = conv.norm
+            (dh,), dg, db = ops.groupnorm_backward([h.t], dy, B, HW, n.num_groups, n.weight.detach().float(),
+                                                   n.bias.detach().float(), n.eps, [h.stats], act=act, dres=dres)
+            return dh, dg, db
+
+        def put(name, g):
+            for k_, v in g.items():
+                grads[name + "." + k_] = v
+
+        dsum = ops.relu_backward(out.t, dout.contiguous())           # d(GN(conv3) + shortcut)
+        dh3, grads["conv3.norm.weight"], grads["conv3.norm.bias"] = gn_bwd(self.conv3, h3, dsum, "none")
+        a2 = self.conv2.norm(h2, act="relu")
+        da2, g = bw.conv2d_backward(self.conv3, a2, dh3)
+        put("conv3", g)
+        dh2, grads["conv2.norm.weight"], grads["conv2.norm.bias"] = gn_bwd(self.conv2, h2, da2, "relu")
+        a1 = self.conv1.norm(h1, act="relu")
+        da1, g = bw.conv2d_backward(self.conv2, a1, dh2)
+        put("conv2", g)
+        dh1, grads["conv1.norm.weight"], grads["conv1.norm.bias"] = gn_bwd(self.conv1, h1, da1, "relu")
+        dx, g = bw.conv2d_backward(self.conv1, xin, dh1, need_dx=need_dx)
+        put("conv1", g)
+        if self.shortcut is not None:
+            dhs, grads["shortcut.norm.weight"], grads["shortcut.norm.bias"] = gn_bwd(self.shortcut, hs, dsum, "none")
+            dx, g = bw.conv2d_backward(self.shortcut, xin, dhs, need_dx=need_dx, dres=dx)
+            put("shortcut", g)
+        elif need_dx:
+            dx = ops.add(dx, dsum)
+        return dx, grads
 
 
 class FeatureExtractorBackbone(nn.Module):
@@ -347,9 +420,49 @@ class AttentionFeatureExtractorBackbone(FeatureExtractorBackbone):
         if self.feature_extractor.ldm_extractor.final_fuse_vae_decoder_feat:
             out_tok['s0'] = features_dict[512]
         projections = self.ema_feature_projections if ema_forward else self.feature_projections
+        tape = getattr(self, "_tape", None)      # set by forward_features_recorded (the training step)
         for idx, name in enumerate(self._out_features):
-            res = 512 // self._out_feature_strides[name]
-            out_tok[name] = projections[idx](features_dict[res])
-        feats = FeatureDict({k: v.nchw() for k, v in out_tok.items()})
+            res = self.feature_res(name)
+            h = features_dict[res]
+            recs = [] if tape is not None else None
+            for blk in projections[idx]:
+                h = blk(h, tape=recs)
+            if tape is not None:
+                tape.append((idx, name, res, recs))
+            out_tok[name] = h
+        if tape is not None:   # training: the head consumes the tokens, no NCHW copies
+            feats = FeatureDict()
+        else:
+            feats = FeatureDict({k: v.nchw() for k, v in out_tok.items()})
         feats.tok = out_tok
         return {'output_features': feats}
+
+    def feature_res(self, name):
+        """Width of the extractor feature that feeds output ``name``: ``512 // stride`` in the reference
+        (feature_extractor.py:383, 512 = backbone_in_size); generalised to the configured backbone_in_size."""
+        return self.backbone_in_size[1] // self._out_feature_strides[name]
+
+    def forward_features_recorded(self, features, input_image_size, tape):
+        """:meth:`forward_features` with the projections' backward records appended to ``tape`` (student projections)."""
+        self._tape = tape
+        try:
+            return self.forward_features(features, input_image_size, ema_forward=False)
+        finally:
+            self._tape = None
+
+    def backward_features(self, tape, dfeats, no_grad_inputs=()):
+        """dfeats: {output name: gradient tokens [M, C_out]} -> ({feature width: gradient tokens of that extractor
+        feature}, {parameter name (relative to the backbone): f32 gradient}).  Inputs whose width is in
+        ``no_grad_inputs`` (the detached VAE-decoder image behind 's0', ldm_diffusers.py:196-201) get no data gradient."""
+        dins, grads = {}, {}
+        for idx, name, res, recs in tape:
+            d = dfeats[name]
+            need_dx = res not in no_grad_inputs
+            for j in reversed(range(len(recs))):
+                d, g = recs[j][0].backward(recs[j], d, need_dx=need_dx or j > 0)
+                for k_, v in g.items():
+                    grads[f"feature_projections.{idx}.{j}.{k_}"] = v
+            if need_dx:
+                assert res not in dins
+                dins[res] = d
+        return dins, grads

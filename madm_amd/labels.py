@@ -86,18 +86,22 @@ def label_classes(labels):
     return torch.nonzero(flags.cpu(), as_tuple=False).flatten().to(torch.int64)
 
 
-def get_class_masks(labels, rng=np.random):
+def get_class_choices(labels, rng=np.random):
     """ClassMix class choice with the reference's RNG calls (dacs_transforms.py:81-90; like there the candidate
-    classes are those of the WHOLE batch): returns one f32 mask [1, 1, H, W] per image, on the device."""
+    classes are those of the WHOLE batch): one int64 tensor of chosen class values per image."""
     ops._need_cuda(labels)
     classes = label_classes(labels)
-    masks = []
-    for label in labels:
+    chosen = []
+    for _ in labels:
         nclasses = classes.shape[0]
         class_choice = rng.choice(nclasses, int((nclasses + nclasses % 2) / 2), replace=False)
-        chosen = classes[torch.Tensor(class_choice).long()]
-        masks.append(class_mix(label, chosen)[0].unsqueeze(0))
-    return masks
+        chosen.append(classes[torch.Tensor(class_choice).long()])
+    return chosen
+
+
+def get_class_masks(labels, rng=np.random):
+    """dacs_transforms.get_class_masks: one f32 mask [1, 1, H, W] per image, on the device."""
+    return [class_mix(label, chosen)[0].unsqueeze(0) for label, chosen in zip(labels, get_class_choices(labels, rng))]
 
 
 def class_mix(label0, chosen, img0=None, img1=None, label1=None):

@@ -46,9 +46,10 @@ class _Packed(nn.Module):
         return tuple(p._version for p in self.parameters(recurse=False)) + \
             tuple(p.data_ptr() for p in self.parameters(recurse=False))
 
-    def _cache_get(self, key, build):
+    def _cache_get(self, key, build, ver=None):
+        """``ver``: the version tuple this entry depends on (default: every own parameter, ``_versions()``)."""
         cache = self.__dict__.setdefault("_pack_cache", {})
-        ver = self._versions()
+        ver = self._versions() if ver is None else ver
         hit = cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]

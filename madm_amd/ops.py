@@ -776,3 +776,149 @@ def confusion_matrix(pred, gt, num_classes, ignore_label, conf=None):
     check(lib.madm_confusion_matrix(pred.contiguous().data_ptr(), gt.contiguous().data_ptr(), pred.numel(), K,
                                     int(ignore_label), conf.data_ptr(), _stream()), "madm_confusion_matrix")
     return conf
+
+
+# ----------------------------------------------------------------------------- training step (csrc/train.hip)
+def scale_channels(x, scale, B, HW, out=None):
+    """x [B*HW, C] (row-strided allowed) * scale f32 [B, C] per (image, channel): Dropout2d and its backward."""
+    _need_cuda(x, scale, out)
+    C = x.shape[1]
+    assert x.stride(1) == 1 and x.shape[0] == B * HW and scale.dtype == torch.float32 and scale.is_contiguous() \
+        and tuple(scale.shape) == (B, C)
+    if out is None:
+        out = torch.empty((x.shape[0], C), dtype=x.dtype, device=x.device)
+    assert out.stride(1) == 1 and out.shape == x.shape and out.dtype == x.dtype
+    check(lib.madm_scale_channels(dtype_code(x), x.data_ptr(), x.stride(0), scale.data_ptr(), out.data_ptr(), out.stride(0),
+                                  B, HW, C, _stream()), "madm_scale_channels")
+    return out
+
+
+def relu_backward(y, dy):
+    """dy where the ReLU OUTPUT y is positive, else 0 (dense tensors of the compute dtype)."""
+    _need_cuda(y, dy)
+    assert y.is_contiguous() and dy.is_contiguous() and y.shape == dy.shape and y.dtype == dy.dtype
+    dx = torch.empty_like(y)
+    check(lib.madm_relu_bwd(dtype_code(y), y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(), _stream()), "madm_relu_bwd")
+    return dx
+
+
+def dwconv3x3_wgrad(x, dy, B, H, W, dilation, dw=None):
+    """f32 [9, C] weight gradient of :func:`dwconv3x3` (before its affine), accumulated into ``dw`` when given."""
+    _need_cuda(x, dy, dw)
+    C = x.shape[1]
+    assert x.is_contiguous() and x.shape[0] == B * H * W and dy.stride(1) == 1 and dy.shape == x.shape and dy.dtype == x.dtype
+    if dw is None:
+        dw = torch.zeros((9, C), dtype=torch.float32, device=x.device)
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and tuple(dw.shape) == (9, C)
+    check(lib.madm_dwconv3x3_wgrad(dtype_code(x), x.data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), B, H, W, C,
+                                   int(dilation), _stream()), "madm_dwconv3x3_wgrad")
+    return dw
+
+
+def resize_bilinear_backward(dout, B, IH, IW, OH, OW):
+    """Adjoint of :func:`resize_bilinear`: dout [B*OH*OW, C] (row-strided allowed) -> din [B*IH*IW, C]."""
+    _need_cuda(dout)
+    C = dout.shape[1]
+    assert dout.stride(1) == 1 and dout.shape[0] == B * OH * OW
+    din = torch.empty((B * IH * IW, C), dtype=dout.dtype, device=dout.device)
+    nbytes = lib.madm_resize_bilinear_bwd_workspace_bytes(B, IW, OH, C)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dout.device)
+    check(lib.madm_resize_bilinear_bwd(dtype_code(dout), dout.data_ptr(), dout.stride(0), din.data_ptr(), B, IH, IW, OH, OW, C,
+                                       ws.data_ptr(), nbytes, _stream()), "madm_resize_bilinear_bwd")
+    return din
+
+
+def softmax_ce(logits, K, labels, weight=None, ignore_index=255, loss_sum=None, gscale=None, coef=1.0, grad_dtype=None,
+               ldd=None):
+    """Pixel-weighted cross entropy on f32 logit tokens [M, >=K]: adds sum_i w_i * CE_i into ``loss_sum`` (f64 [1]) and /
+    or returns dlogits [M, ldd] of ``grad_dtype`` = coef * gscale * w_i * (softmax - onehot).  Returns (loss_sum, dlogits)."""
+    _need_cuda(logits, labels, weight, loss_sum, gscale)
+    M = logits.shape[0]
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and logits.shape[1] >= K
+    labels = labels.reshape(-1)
+    assert labels.dtype == torch.int64 and labels.is_contiguous() and labels.numel() == M
+    if weight is not None:
+        weight = weight.reshape(-1)
+        assert weight.dtype == torch.float32 and weight.is_contiguous() and weight.numel() == M
+    assert loss_sum is None or (loss_sum.dtype == torch.float64 and loss_sum.numel() == 1)
+    assert gscale is None or (gscale.dtype == torch.float32 and gscale.numel() == 1)
+    dl = None
+    dt = MADM_F32
+    if grad_dtype is not None:
+        ldd = k_tile(grad_dtype) if ldd is None else ldd
+        dl = torch.empty((M, ldd), dtype=grad_dtype, device=logits.device)
+        dt = dtype_code(grad_dtype)
+    check(lib.madm_softmax_ce(dt, logits.data_ptr(), logits.stride(0), K, labels.data_ptr(), _ptr(weight), int(ignore_index),
+                              M, _ptr(loss_sum), _ptr(gscale), float(coef), _ptr(dl), 0 if dl is None else dl.stride(0),
+                              _stream()), "madm_softmax_ce")
+    return loss_sum, dl
+
+
+def masked_l1(pred, gt, mask=None, l2=False, loss_sum=None, gscale=None, coef=1.0, want_grad=False):
+    """sum |pred - gt| * nearest(mask) (or the squared difference) over NCHW f32 tensors into ``loss_sum`` (f64 [1]) and /
+    or the gradient w.r.t. pred (coef * gscale * mask * sign / 2 d).  mask: f32 [B, 1, Hm, Wm] or None."""
+    _need_cuda(pred, gt, mask, loss_sum, gscale)
+    B, C, h, w = pred.shape
+    assert pred.dtype == torch.float32 and pred.is_contiguous() and gt.dtype == torch.float32 and gt.is_contiguous() \
+        and gt.shape == pred.shape
+    Hm = Wm = 0
+    if mask is not None:
+        assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.shape[0] == B and mask.numel() == B * mask.shape[-2] * mask.shape[-1]
+        Hm, Wm = mask.shape[-2:]
+    dp = torch.empty_like(pred) if want_grad else None
+    check(lib.madm_masked_l1(pred.data_ptr(), gt.data_ptr(), _ptr(mask), B, C, h, w, Hm, Wm, 1 if l2 else 0, _ptr(loss_sum),
+                             _ptr(gscale), float(coef), _ptr(dp), _stream()), "madm_masked_l1")
+    return loss_sum, dp
+
+
+def tanh_gate_backward(dout, x1, a1=None, x2=None, a2=None, da1=None, dx1=None, da2=None, dx2=None):
+    """Backward of :func:`tanh_gate` for dout [repeat, n]: ACCUMULATES into the given f32 gradient buffers."""
+    _need_cuda(dout, x1, a1, x2, a2, da1, dx1, da2, dx2)
+    n = x1.numel()
+    assert dout.dtype == torch.float32 and dout.is_contiguous() and dout.numel() % n == 0
+    for t in (x1, a1, x2, a2, da1, dx1, da2, dx2):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n)
+    check(lib.madm_tanh_gate_bwd(_ptr(a1), x1.data_ptr(), _ptr(a2), _ptr(x2), dout.data_ptr(), _ptr(da1), _ptr(dx1), _ptr(da2),
+                                 _ptr(dx2), n, dout.numel() // n, _stream()), "madm_tanh_gate_bwd")
+
+
+def batch_stats(x, stats=None, running=None, momentum=0.1):
+    """f64 [1, C, 2] sum / sum of squares of x [M, C] over ALL rows -- the statistics of a train-mode BatchNorm2d over
+    channels-last tokens.  ``stats``: per-image sums [B, C, 2] from a producing conv's epilogue (computed here when None);
+    ``running`` = (running_mean, running_var) f32 [C] buffers updated like nn.BatchNorm2d does in train mode."""
+    M, C = x.shape
+    if stats is None:
+        stats = torch.zeros((1, C, 2), dtype=torch.float64, device=x.device)
+        groupnorm_stats(x, 1, M, stats)
+    assert stats.dtype == torch.float64 and stats.is_contiguous() and stats.shape[1] == C
+    st = torch.empty((1, C, 2), dtype=torch.float64, device=x.device)
+    rm, rv = running if running is not None else (None, None)
+    _need_cuda(stats, rm, rv)
+    assert rm is None or (rm.dtype == torch.float32 and rm.is_contiguous() and rv.dtype == torch.float32 and rv.is_contiguous())
+    check(lib.madm_bn_fold_stats(stats.data_ptr(), stats.shape[0], C, float(M), float(momentum), st.data_ptr(), _ptr(rm),
+                                 _ptr(rv), _stream()), "madm_bn_fold_stats")
+    return st
+
+
+def batchnorm_train(x, st, gamma, beta, eps, act=None, out=None):
+    """Train-mode BatchNorm2d (+act) on tokens x [M, C] with batch statistics ``st`` (:func:`batch_stats`): GroupNorm with
+    one image of M pixels and one group per channel (biased variance, like nn.BatchNorm2d's normalisation).  ``out`` may be
+    a column window of a wider buffer."""
+    _need_cuda(x, st, gamma, beta, out)
+    M, C = x.shape
+    assert x.is_contiguous() and st.dtype == torch.float64 and st.is_contiguous() and st.numel() == 2 * C
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.stride(1) == 1 and out.shape == x.shape and out.dtype == x.dtype
+    check(lib.madm_groupnorm_apply(dtype_code(x), x.data_ptr(), out.data_ptr(), out.stride(0), 1, M, C, 0, C, C,
+                                   st.data_ptr(), C, None, gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                   _act_code(act=act), None, 0, _stream()), "madm_groupnorm_apply")
+    return out
+
+
+def batchnorm_backward(x, st, dy, gamma, beta, eps, act=None):
+    """Backward of :func:`batchnorm_train`: (dx, dgamma, dbeta); dy may be a row-strided column window."""
+    M, C = x.shape
+    (dx,), dg, db = groupnorm_backward([x], dy, 1, M, C, gamma, beta, eps, [st], act=act)
+    return dx, dg, db

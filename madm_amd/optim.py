@@ -81,3 +81,38 @@ def ema_update(ema_flat, param_flat, alpha):
     assert ema_flat.numel() == param_flat.numel() and ema_flat.dtype == torch.float32
     check(lib.madm_ema_update(ema_flat.data_ptr(), param_flat.data_ptr(), ema_flat.numel(), float(alpha), _stream()),
           "madm_ema_update")
+
+
+class EmaPairs:
+    """CMDISE._update_ema (modeling/meta_arch/cmdise.py:337-349) for a list of (teacher, student) parameter pairs: runs of
+    pairs that are adjacent in memory on both sides (parameters living in FlatParams buffers, laid out in the same order)
+    are updated by ONE madm_ema_update launch each; isolated tensors get their own launch.  Parameter versions are moved
+    afterwards so packed operands derived from the teacher are refreshed."""
+
+    def __init__(self, teacher_params, student_params):
+        self.pairs = [(t, s) for t, s in zip(teacher_params, student_params)]
+        assert all(t.shape == s.shape and t.dtype == torch.float32 and s.dtype == torch.float32 for t, s in self.pairs)
+        self._spans = None
+        self._key = None
+
+    def _build(self):
+        spans = []   # [teacher ptr, student ptr, bytes]
+        for t, s in self.pairs:
+            tp, sp, nb = t.data_ptr(), s.data_ptr(), t.numel() * 4
+            if spans:
+                lt, ls, lb = spans[-1]
+                gap = tp - (lt + lb)
+                if 0 <= gap < 16 and sp - (ls + lb) == gap and (lb + gap) % 4 == 0:
+                    spans[-1][2] = lb + gap + nb
+                    continue
+            spans.append([tp, sp, nb])
+        return spans
+
+    def update(self, alpha):
+        key = tuple((t.data_ptr(), s.data_ptr()) for t, s in self.pairs)
+        if key != self._key:
+            self._key, self._spans = key, self._build()
+        for tp, sp, nb in self._spans:
+            check(lib.madm_ema_update(ctypes.c_void_p(tp), ctypes.c_void_p(sp), nb // 4, float(alpha), _stream()),
+                  "madm_ema_update")
+        torch.autograd.graph.increment_version([t for t, _ in self.pairs])

@@ -130,6 +130,82 @@ def main_slide():
     print(f"slide_s345: {time.time() - t0:.1f}s", {k: v.shape for k, v in out.items()})
 
 
+def build_train_oracle(reference=True):
+    """OracleMTMADISE of the Depth config at TRAIN_CASE size; ``reference``: the REFERENCE's DAFormerHead class and
+    CmdiseCriterion (this container), else the oracle's restatements (anywhere)."""
+    from oracle import madm_path, train_path
+    from golden_util import TRAIN_CASE, train_palette, train_dropout_scales
+    cfg = madm_path.DEPTH_CFG
+    vae, unet = build_oracle(lora=False)
+    crit = train_path.reference_criterion() if reference else None
+    model = train_path.build(vae, unet, cfg, criterion_cls=crit, in_size=TRAIN_CASE["size"],
+                             train_palette=train_palette(TRAIN_CASE["K"]), pseudo_threshold=TRAIN_CASE["pseudo_threshold"])
+    if reference:
+        ns = ref_driver.load_modeling()
+        n = len(cfg["out_features"])
+        head = ns.daformer_head.DAFormerHead(
+            in_channels=list(cfg["head_in_channels"]), in_keys=list(cfg["out_features"]), in_index=list(range(n)),
+            channels=256, dropout_ratio=0.1, num_classes=cfg["num_classes"], norm_cfg=dict(type='BN', requires_grad=True),
+            align_corners=False, decoder_params=madm_path.head_decoder_params())
+        head.dropout = train_path.FixedDropout2d()
+        model.sem_seg_head = model.sem_seg_head_sec_modal = head
+    init_eval_params(model.backbone, model.sem_seg_head)
+    for m in (model.backbone.feature_extractor.ldm_extractor.unet.conv_norm_out,
+              model.backbone.feature_extractor.ldm_extractor.unet.conv_out):      # exclude_unused_params (ldm_diffusers.py:123-141)
+        for p in m.parameters():
+            p.requires_grad = False
+    model._inti_ema_weights()           # teacher = copy of the initialised student (cmdise.py:307-335)
+    model.train()
+    model.backbone.feature_extractor.ldm_extractor.vae.eval()
+    model.backbone.feature_extractor.ldm_extractor.unet.eval()                   # LdmDiffusers._freeze: train(mode=False)
+    sc = train_dropout_scales(TRAIN_CASE["B"])
+    model.sem_seg_head.dropout.scales = [sc[0], sc[1]]
+    model.ema_sem_seg_head.dropout.scales = [sc[2]]
+    return model
+
+
+def run_train_step(model):
+    import random
+    from golden_util import TRAIN_CASE, train_inputs, grad_summary
+    random.seed(TRAIN_CASE["py_seed"])
+    np.random.seed(TRAIN_CASE["np_seed"])
+    losses = model.forward_train(train_inputs(**TRAIN_CASE))
+    total = sum(losses.values())
+    total.backward()
+    named = [(n, p.grad) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
+    names, rows, full = grad_summary(named, TRAIN_CASE["full_grad_max_numel"])
+    out = {"loss_" + k: np.array(v.item(), dtype=np.float64) for k, v in losses.items()}
+    out["grad_names"] = np.array("\n".join(names))
+    out["grad_rows"] = rows
+    for n, g in full.items():
+        out["grad:" + n] = g.numpy()
+    ls = model.last_step
+    out["mixed_lbl"] = ls["mixed_lbl"].to(torch.uint8).numpy()
+    out["pseudo_label"] = ls["pseudo_label"].to(torch.uint8).numpy()
+    out["pseudo_weight0"] = np.array(ls["pseudo_weight"].flatten()[0].item())
+    out["mixed_seg_weight"] = ls["mixed_seg_weight"].numpy()
+    out["source_logits"] = ls["source_logits"].detach().numpy()
+    out["target_logits"] = ls["target_logits"].detach().numpy()
+    out["ema_logits"] = ls["ema_logits"].detach().numpy()
+    for tag, head in (("student", model.sem_seg_head), ("teacher", model.ema_sem_seg_head)):
+        for n, b in head.named_buffers():
+            if n.endswith("running_mean") or n.endswith("running_var"):
+                out[f"bn:{tag}:{n}"] = b.numpy().copy()
+    return out
+
+
+def main_train():
+    """One training step (mtmadise.py:180-656, shipped Depth flags, 64 x 64) through oracle/train_path.OracleMTMADISE with
+    the REFERENCE's DAFormerHead and CmdiseCriterion; losses, gradient checksums of every trainable tensor, full
+    gradients of the small non-UNet tensors, pseudo labels and BatchNorm running statistics."""
+    torch.set_num_threads(os.cpu_count())
+    t0 = time.time()
+    out = run_train_step(build_train_oracle(reference=True))
+    np.savez_compressed(os.path.join(HERE, "train_depth.npz"), **out)
+    print(f"train_depth: {time.time() - t0:.1f}s", {k: float(v) for k, v in out.items() if k.startswith("loss_")},
+          len(out["grad_rows"]), "gradient tensors")
+
+
 def main_labels():
     """Label pipeline through the REFERENCE's own functions (extracted by AST from mtmadise.py / dacs_transforms.py,
     oracle/labels.reference_functions): palette conversion, ClassMix masks with a seeded numpy RNG, one_mix; the
@@ -153,6 +229,8 @@ def main_labels():
 
 
 if __name__ == "__main__":
+    if "train_depth" in sys.argv[1:] or not sys.argv[1:]:
+        main_train()
     if "labels" in sys.argv[1:] or not sys.argv[1:]:
         main_labels()
     if "slide_s345" in sys.argv[1:] or not sys.argv[1:]:

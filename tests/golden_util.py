@@ -29,7 +29,7 @@ def make_inputs(B, H, W, t, cond_scale, **_):
 
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
-    return {k: torch.from_numpy(z[k]) for k in z.files}
+    return {k: torch.from_numpy(z[k]) for k in z.files if z[k].dtype.kind in 'fiub'}
 
 
 def add_lora(unet, LoraConfig, seed=WEIGHT_SEED):
@@ -94,3 +94,52 @@ def label_inputs(B, K, H, W, **_):
     logits = 3.0 * torch.randn((B, K, H // 4, W // 4), generator=g)
     imgs = torch.randn((B, 3, H, W), generator=g)
     return {"label": lab, "palette": palette, "logits": logits, "imgs": imgs}
+
+
+# ---- one training step of the shipped RGB->Depth configuration at 64 x 64 (tests/golden/train_depth.npz) --------------
+TRAIN_CASE = dict(B=2, size=64, K=11, py_seed=20240, np_seed=20241, full_grad_max_numel=70000,
+                  pseudo_threshold=0.25)     # low threshold: random-weight teachers are never 96.8 % confident
+
+
+def train_inputs(B, size, K, **_):
+    """list[dict] as the dataset mapper hands it over (data/dataset/cross_modality_dataset.py:423-521): 0..255 images,
+    int64 labels with ~6 % ignore pixels."""
+    g = torch.Generator().manual_seed(8899)
+    out = []
+    for _i in range(B):
+        lab = torch.randint(0, K, (1, size // 8, size // 8), generator=g)
+        lab = lab.repeat_interleave(8, 1).repeat_interleave(8, 2)             # blocky regions, like real label maps
+        noise = torch.rand((1, size, size), generator=g)
+        lab[noise < 0.06] = 255
+        out.append({"source_rgb": 255.0 * torch.rand((3, size, size), generator=g), "source_label": lab.long(),
+                    "target_second_modality": 255.0 * torch.rand((3, size, size), generator=g),
+                    "width": size, "height": size})
+    return out
+
+
+def train_palette(K):
+    return [int(v) for v in torch.randint(0, 256, (K * 3,), generator=torch.Generator().manual_seed(99))]
+
+
+def train_dropout_scales(B, C=256, p=0.1, n=3):
+    """Injected Dropout2d keep-scales of the head calls in call order: source, target (student head), teacher."""
+    g = torch.Generator().manual_seed(515)
+    return [(torch.rand((B, C), generator=g) >= p).float() / (1.0 - p) for _ in range(n)]
+
+
+def grad_probe(name, shape, seed=7):
+    """Seeded unit-variance probe vector of a gradient tensor (its dot product is a checksum of the whole tensor)."""
+    from madm_amd import weights
+    return torch.randn(shape, generator=weights._gen(seed, "probe." + name))
+
+
+def grad_summary(named_grads, full_max):
+    """{name: grad} -> (names, [n, 2] f64 array of (l2 norm, probe dot), {name: full tensor for small ones})."""
+    names, rows, full = [], [], {}
+    for n, g in named_grads:
+        g = g.detach().double().cpu()
+        names.append(n)
+        rows.append([g.norm().item(), (g * grad_probe(n, g.shape).double()).sum().item()])
+        if g.numel() <= full_max and ".unet." not in n:
+            full[n] = g.float()
+    return names, np.array(rows, dtype=np.float64), full

@@ -1,0 +1,274 @@
+"""Training step of the path on the HIP kernels (BASELINE config 4): the new kernels against
+the matching torch-CPU ops with autograd, and ONE FULL STEP (source pass + target pass + teacher pass, every loss, every
+gradient) against the committed fixture that oracle/train_path.OracleMTMADISE produced with the reference's own
+DAFormerHead and CmdiseCriterion (tests/golden/gen_golden.py::main_train).
+
+Tolerances: f32 mode <= 1e-3 relative (north_star); 16-bit modes are reported and bounded loosely (gradients through ~250
+layers in 16-bit storage)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import (TRAIN_CASE, train_inputs, train_palette, train_dropout_scales, grad_probe, init_eval_params,
+                         load_golden)
+from util import rel_err, to_tokens, from_tokens
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.bfloat16, torch.float16]
+IDS = ["f32", "bf16", "f16"]
+
+
+def _q(x, dtype):
+    return x.to(dtype).float()
+
+
+def _tol(dtype, f32=1e-5, b16=2e-2, f16=3e-3):
+    return {torch.float32: f32, torch.bfloat16: b16, torch.float16: f16}[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT, ids=IDS)
+def test_batchnorm_train_is_groupnorm_over_the_batch(cuda, dtype):
+    """Train-mode BatchNorm2d(+ReLU) forward, running-statistic update and backward vs torch."""
+    from madm_amd import ops
+    B, C, H, W = 2, 64, 12, 20
+    g = torch.Generator().manual_seed(3)
+    x = _q(torch.randn((B, C, H, W), generator=g) * 2 + 0.5, dtype)
+    dy = _q(torch.randn((B, C, H, W), generator=g), dtype)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(C, generator=g)); bn.bias.copy_(0.3 * torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g)); bn.running_var.copy_(0.5 + torch.rand(C, generator=g))
+    rm, rv = bn.running_mean.clone().cuda(), bn.running_var.clone().cuda()
+    xr = x.clone().requires_grad_(True)
+    y = F.relu(bn(xr))
+    y.backward(dy)
+    xt, dyt = to_tokens(x, dtype), to_tokens(dy, dtype)
+    sums = torch.zeros((B, C, 2), dtype=torch.float64, device="cuda")
+    ops.groupnorm_stats(xt, B, H * W, sums)
+    st = ops.batch_stats(xt, sums, running=(rm, rv), momentum=0.1)
+    gam, bet = bn.weight.detach().cuda(), bn.bias.detach().cuda()
+    out = torch.zeros((B * H * W, 2 * C), dtype=dtype, device="cuda")
+    ops.batchnorm_train(xt, st, gam, bet, bn.eps, act="relu", out=out[:, C:])          # into a column window
+    dx, dg, db = ops.batchnorm_backward(xt, st, dyt, gam, bet, bn.eps, act="relu")
+    torch.cuda.synchronize()
+    t = _tol(dtype)
+    assert rel_err(from_tokens(out[:, C:], B, H, W), y.detach())[0] < max(t, 2e-6) and out[:, :C].abs().max() == 0
+    assert rel_err(from_tokens(dx, B, H, W), xr.grad)[0] < max(10 * t, 1e-5)
+    assert rel_err(dg.cpu(), bn.weight.grad)[0] < max(t, 1e-5) and rel_err(db.cpu(), bn.bias.grad)[0] < max(t, 1e-5)
+    assert rel_err(rm.cpu(), bn.running_mean)[0] < 1e-6 and rel_err(rv.cpu(), bn.running_var)[0] < 1e-6
+    st2 = ops.batch_stats(xt)                                                          # statistics computed in place
+    assert rel_err(st2.cpu(), st.cpu())[0] < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT, ids=IDS)
+def test_dropout_relu_dwconv_grad_kernels(cuda, dtype):
+    from madm_amd import ops
+    B, C, H, W, dil = 2, 64, 20, 24, 6
+    g = torch.Generator().manual_seed(4)
+    x = _q(torch.randn((B, C, H, W), generator=g), dtype)
+    dy = _q(torch.randn((B, C, H, W), generator=g), dtype)
+    w = torch.randn((C, 1, 3, 3), generator=g) / 3
+    s = (torch.rand((B, C), generator=g) >= 0.1).float() / 0.9
+    xt, dyt = to_tokens(x, dtype), to_tokens(dy, dtype)
+    # Dropout2d scale
+    assert rel_err(from_tokens(ops.scale_channels(xt, s.cuda(), B, H * W), B, H, W), x * s[:, :, None, None])[0] < _tol(dtype, 1e-6, 8e-3, 1e-3)
+    # ReLU backward from the output
+    yr = F.relu(x)
+    assert torch.equal(from_tokens(ops.relu_backward(to_tokens(yr, dtype), dyt), B, H, W), dy * (yr > 0))
+    # depthwise dilated conv: weight gradient + data gradient (the same conv with reversed taps)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, padding=dil, dilation=dil, groups=C).backward(dy)
+    dw = ops.dwconv3x3_wgrad(xt, dyt, B, H, W, dil)
+    assert rel_err(dw.t().reshape(C, 1, 3, 3).cpu(), wr.grad)[0] < _tol(dtype, 2e-5, 2e-5, 2e-5)       # f32 accumulation of exact products
+    w9c = w.reshape(C, 9).t().contiguous().cuda()
+    one, zero = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = ops.dwconv3x3(dyt, w9c.flip(0).contiguous(), one, zero, B, H, W, dil, 0)
+    assert rel_err(from_tokens(dx, B, H, W), xr.grad)[0] < _tol(dtype, 1e-5, 8e-3, 1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT, ids=IDS)
+@pytest.mark.parametrize("geom", [(5, 7, 40, 56), (16, 16, 64, 64), (24, 24, 24, 24), (9, 30, 17, 11)])
+def test_resize_bilinear_backward_is_the_adjoint(cuda, dtype, geom):
+    from madm_amd import ops
+    IH, IW, OH, OW = geom
+    B, C = 2, 16
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((B, C, IH, IW), generator=g, requires_grad=True)
+    dy = _q(torch.randn((B, C, OH, OW), generator=g), dtype)
+    F.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=False).backward(dy)
+    wide = torch.zeros((B * OH * OW, 3 * C), dtype=dtype, device="cuda")
+    wide[:, C:2 * C] = to_tokens(dy, dtype)
+    dx = ops.resize_bilinear_backward(wide[:, C:2 * C], B, IH, IW, OH, OW)            # row-strided gradient window
+    assert rel_err(from_tokens(dx, B, IH, IW), x.grad)[0] < _tol(dtype, 2e-6, 8e-3, 1e-3)
+
+
+@pytest.mark.parametrize("dtype", DT, ids=IDS)
+def test_softmax_ce_loss_and_gradient(cuda, dtype):
+    """CmdiseCriterion.cross_entropy (criterion.py:120-131): ignore index, pixel weights, mean over ALL pixels."""
+    from madm_amd import ops
+    B, K, H, W = 2, 11, 9, 13
+    g = torch.Generator().manual_seed(6)
+    logits = (3 * torch.randn((B, K, H, W), generator=g)).requires_grad_(True)
+    label = torch.randint(0, K, (B, H, W), generator=g)
+    label[torch.rand((B, H, W), generator=g) < 0.2] = 255
+    pw = torch.rand((B, H, W), generator=g)
+    M = B * H * W
+    for weight in (None, pw):
+        logits.grad = None
+        loss = F.cross_entropy(logits, label, reduction='none', ignore_index=255)
+        loss = (loss * weight if weight is not None else loss).mean() * 1.7
+        loss.backward()
+        lt = logits.detach().permute(0, 2, 3, 1).reshape(M, K)
+        ltp = torch.nn.functional.pad(lt, (0, 1)).contiguous().cuda()                  # [M, 12] f32 tokens, K valid
+        s = torch.zeros(1, dtype=torch.float64, device="cuda")
+        gs = torch.tensor([2.0], device="cuda")
+        _, d = ops.softmax_ce(ltp, K, label.cuda(), None if weight is None else weight.cuda(), 255, loss_sum=s)
+        _, d = ops.softmax_ce(ltp, K, label.cuda(), None if weight is None else weight.cuda(), 255, gscale=gs,
+                              coef=1.7 / M, grad_dtype=dtype)
+        assert abs(s.item() * 1.7 / M - loss.item()) < 1e-5 * abs(loss.item())
+        got = d.float().cpu()
+        assert got.shape[1] == (32 if dtype == torch.float32 else 64) and got[:, K:].abs().max() == 0
+        ref = 2.0 * logits.grad.permute(0, 2, 3, 1).reshape(M, K)
+        assert rel_err(got[:, :K], ref)[0] < _tol(dtype, 1e-5, 8e-3, 1e-3)
+
+
+def test_masked_l1_and_tanh_gate_backward(cuda):
+    from madm_amd import ops
+    g = torch.Generator().manual_seed(7)
+    B, C, h, w = 2, 4, 8, 8
+    pred = torch.randn((B, C, h, w), generator=g, requires_grad=True)
+    gt = torch.randn((B, C, h, w), generator=g)
+    mask = torch.rand((B, 1, 64, 64), generator=g)
+    for l2 in (False, True):
+        pred.grad = None
+        d = F.mse_loss(pred, gt, reduction='none') if l2 else F.l1_loss(pred, gt, reduction='none')
+        m = F.interpolate(mask, size=(h, w), mode='nearest').repeat(1, C, 1, 1)
+        loss = torch.sum(d * m) / d.numel() * 0.7
+        loss.backward()
+        s = torch.zeros(1, dtype=torch.float64, device="cuda")
+        ops.masked_l1(pred.detach().cuda(), gt.cuda(), mask.cuda(), l2=l2, loss_sum=s)
+        _, dp = ops.masked_l1(pred.detach().cuda(), gt.cuda(), mask.cuda(), l2=l2, gscale=torch.tensor([3.0], device="cuda"),
+                              coef=0.7 / d.numel(), want_grad=True)
+        assert abs(s.item() * 0.7 / d.numel() - loss.item()) < 1e-6 * abs(loss.item())
+        assert rel_err(dp.cpu(), 3.0 * pred.grad)[0] < 1e-6
+    # tanh gates
+    n, R = 77 * 768, 2
+    a1, x1, a2, x2 = [torch.randn(n, generator=g).requires_grad_(True) for _ in range(4)]
+    out = (torch.tanh(a1) * x1 + torch.tanh(a2) * x2)[None].repeat(R, 1)
+    do = torch.randn((R, n), generator=g)
+    out.backward(do)
+    bufs = [torch.zeros(n, device="cuda") for _ in range(4)]
+    ops.tanh_gate_backward(do.cuda(), x1.detach().cuda(), a1.detach().cuda(), x2.detach().cuda(), a2.detach().cuda(),
+                           da1=bufs[0], dx1=bufs[1], da2=bufs[2], dx2=bufs[3])
+    for b_, r_ in zip(bufs, (a1, x1, a2, x2)):
+        assert rel_err(b_.cpu(), r_.grad)[0] < 1e-5
+
+
+# ----------------------------------------------------------------------------- one full training step
+def build_product_train(dtype, **kw):
+    from madm_amd.ldm_rocm import LdmRocm
+    from madm_amd.backbone import BasePromptTimeGenerator, AttentionFeatureExtractorBackbone
+    from madm_amd.head import DAFormerHead
+    from madm_amd.criterion import CmdiseCriterion
+    from madm_amd.mtmadise import MTMADISE
+    from oracle import madm_path
+    cfg = madm_path.DEPTH_CFG
+    size = kw.pop("size", TRAIN_CASE["size"])
+    ldm = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=(),
+                  input_range='-1+1', unet_block_indices_type='after', finetune_unet='all', compute_dtype=dtype,
+                  weights='synthetic', seed=0, vae_decoder_loss=True)
+    gen = BasePromptTimeGenerator(learnable_cond_prompt=True, learnable_cond_time=True, clip_state='no', num_timesteps=1,
+                                  clip_model_name="ViT-L-14-336", ldm_extractor=ldm, same_cond_params=True)
+    backbone = AttentionFeatureExtractorBackbone(
+        attention_features_res=None, feature_dims=list(cfg["feature_dims"]), projection_dim=list(cfg["projection_dim"]),
+        attention_features_location=None, feature_extractor=gen, num_res_blocks=1, out_features=list(cfg["out_features"]),
+        backbone_in_size=(size, size))
+    n = len(cfg["out_features"])
+    head = DAFormerHead(in_channels=list(cfg["head_in_channels"]), in_keys=list(cfg["out_features"]), in_index=list(range(n)),
+                        channels=256, dropout_ratio=0.1, num_classes=cfg["num_classes"], norm_cfg=dict(type='BN'),
+                        align_corners=False, decoder_params=madm_path.head_decoder_params())
+    init_eval_params(backbone, head)
+    args = dict(target_modality="Depth", train_palette=train_palette(cfg["num_classes"]), vae_decoder_loss='st',
+                vae_decoder_loss_type='L1', vae_decoder_loss_weight=[1.0, 1.0], reg_uncertain=True, rev_noise_sup=True,
+                rev_noise_end_iter=5000, rev_noise_gradually=True, denoise_timestep_range=[60, 61], max_iter=10000,
+                pseudo_threshold=TRAIN_CASE["pseudo_threshold"], color_aug_flag=False)
+    args.update(kw)
+    model = MTMADISE(backbone.cuda(), head.cuda(), CmdiseCriterion(num_classes=cfg["num_classes"]), **args)
+    return model.train()
+
+
+@pytest.mark.parametrize("dtype", DT, ids=IDS)
+def test_train_step_matches_fixture(cuda, dtype):
+    """model(list[dict]) -> loss dict; sum(losses).backward(): every loss scalar, the pseudo labels / mixed labels (bit
+    exact in f32 mode), the BatchNorm running statistics and the gradient of EVERY trainable tensor (l2 norm and a seeded
+    probe checksum; the small non-UNet tensors in full) vs tests/golden/train_depth.npz."""
+    gold = load_golden("train_depth")
+    model = build_product_train(dtype)
+    sc = train_dropout_scales(TRAIN_CASE["B"])
+    model.sem_seg_head.dropout_scale_override = [sc[0], sc[1]]
+    model.ema_sem_seg_head.dropout_scale_override = [sc[2]]
+    random.seed(TRAIN_CASE["py_seed"])
+    np.random.seed(TRAIN_CASE["np_seed"])
+    losses = model(train_inputs(**TRAIN_CASE))
+    assert set(losses) == {"source_loss", "target_loss", "vae_decoder_source_loss", "vae_decoder_target_loss"}
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    f32 = dtype == torch.float32
+    ltol = 1e-4 if f32 else (1e-2 if dtype == torch.float16 else 5e-2)
+    rep = []
+    for k, v in losses.items():
+        ref = gold["loss_" + k].item()
+        rep.append(f"{k} {v.item():.6f} / {ref:.6f}")
+        assert abs(v.item() - ref) <= ltol * max(abs(ref), 1e-3), rep[-1]
+    print(dtype, "; ".join(rep))
+    ls = model.last_step
+    if f32:
+        assert torch.equal(ls["pseudo_label"].cpu().to(torch.uint8), gold["pseudo_label"])
+        assert torch.equal(ls["mixed_lbl"].cpu().to(torch.uint8), gold["mixed_lbl"])
+        assert abs(ls["pseudo_weight"].flatten()[0].item() - gold["pseudo_weight0"].item()) < 1e-6
+        assert rel_err(ls["mixed_seg_weight"].cpu(), gold["mixed_seg_weight"])[0] < 1e-6
+    else:
+        assert (ls["pseudo_label"].cpu().to(torch.uint8) == gold["pseudo_label"]).float().mean() > 0.9
+    K = 11
+    for name in ("source_logits", "target_logits"):
+        t = ls[name]
+        got = from_tokens(t.t[:, :K], t.B, t.H, t.W)
+        e, l2 = rel_err(got, gold[name])
+        assert (e < 1e-3) if f32 else (l2 < (2e-2 if dtype == torch.float16 else 1e-1)), (name, e, l2)
+    # gradients
+    import numpy as _np
+    z = _np.load(__import__("os").path.join(__import__("golden_util").GOLDEN_DIR, "train_depth.npz"))
+    names = str(z["grad_names"]).split("\n")
+    rows = z["grad_rows"]
+    params = dict(model.named_parameters())
+    missing = [n for n in names if n not in params or params[n].grad is None]
+    assert not missing, missing[:5]
+    extra = [n for n, p in params.items() if p.requires_grad and p.grad is not None and n not in set(names)]
+    assert not extra, extra[:5]
+    worst = (0.0, "")
+    gtol = 1e-3 if f32 else (6e-2 if dtype == torch.float16 else 3e-1)
+    for n, (norm, dot) in zip(names, rows):
+        g = params[n].grad.detach().double().cpu()
+        gn = g.norm().item()
+        gd = (g * grad_probe(n, g.shape).double()).sum().item()
+        scale = max(norm, 1e-12)
+        # a probe dot product has standard deviation ~ |g|: compare both on the scale of the gradient's norm
+        err = max(abs(gn - norm), abs(gd - dot)) / scale
+        if norm < 1e-9:
+            assert gn < 1e-6, (n, gn)
+            continue
+        if err > worst[0]:
+            worst = (err, n)
+        assert err < gtol, (n, gn, norm, gd, dot)
+    print(dtype, "worst gradient checksum error", worst)
+    for k in z.files:
+        if k.startswith("grad:"):
+            e = rel_err(params[k[5:]].grad.cpu(), torch.from_numpy(z[k]))[0]
+            assert e < (1e-3 if f32 else (8e-2 if dtype == torch.float16 else 4e-1)), (k, e)
+        if k.startswith("bn:") and f32:
+            _, tag, bname = k.split(":", 2)
+            head = model.sem_seg_head if tag == "student" else model.ema_sem_seg_head
+            assert rel_err(dict(head.named_buffers())[bname].cpu(), torch.from_numpy(z[k]))[0] < 1e-4, k
