@@ -406,6 +406,13 @@ int madm_adamw_step(float* p, const float* g, float* m, float* v, size_t n, floa
                     float eps, float weight_decay, int step, float grad_scale, void* stream);
 /* ema = alpha * ema + (1 - alpha) * p : CMDISE._update_ema (modeling/meta_arch/cmdise.py:337-349), one launch for all
  * teacher parameters instead of a Python loop over tensors. */
+/* The same step with PER-TENSOR hyper-parameters (get_default_optimizer_params_unet, utils/parameter_count.py:120-215:
+ * weight_decay_norm = weight_decay_bias = 0, optional unet_lr; torch.optim.AdamW skipping parameters without a gradient):
+ * the flat buffers are laid out in 1024-element chunks that never straddle two tensors, chunk_tensor[n / 1024] (int32) names
+ * each chunk's tensor and hyper[tensor] = {lr, weight_decay, 1 - beta1^step_t, sqrt(1 - beta2^step_t)} (f32 x 4, 16-byte
+ * aligned; a zero third entry skips the tensor this step). */
+int madm_adamw_step_table(float* p, const float* g, float* m, float* v, size_t n, const int* chunk_tensor, const float* hyper,
+                          float beta1, float beta2, float eps, float grad_scale, void* stream);
 int madm_ema_update(float* ema, const float* p, size_t n, float alpha, void* stream);
 
 /* ---- label / pseudo-label pipeline of the self-training step, on the device (bit-exact index work) --------------

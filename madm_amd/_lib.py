@@ -144,6 +144,8 @@ SYMBOLS = [
     ("madm_sumsq_f32", c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     ("madm_adamw_step", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float, c_float,
                                 c_int, c_float, c_void_p]),
+    ("madm_adamw_step_table", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_float, c_float,
+                                      c_float, c_float, c_void_p]),
     ("madm_ema_update", c_int, [c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     ("madm_label_to_rgb", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     ("madm_pseudo_label", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),

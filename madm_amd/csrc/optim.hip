@@ -57,6 +57,29 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         for (size_t i = n4 * 4; i < n; ++i) adamw1(p[i], g[i], m[i], v[i], a);
 }
 
+// per-tensor hyper-parameters: the flat buffer is laid out in 1024-element chunks that never straddle two tensors
+// (optim.FlatParams(align=1024)); chunk_tensor[c] names the tensor of chunk c and hyper[t] = {lr, weight_decay, bias
+// correction 1, sqrt(bias correction 2)} -- bc1 == 0 marks a tensor that is skipped this step (no gradient arrived:
+// torch.optim.AdamW leaves such parameters, their moments and their step counts untouched).
+__global__ __launch_bounds__(256) void adamw_table_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, size_t nchunks,
+                                                          const int* __restrict__ chunk_tensor,
+                                                          const float4* __restrict__ hyper, float beta1, float beta2,
+                                                          float eps, float gscale) {
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const float4 h = hyper[chunk_tensor[c]];
+        if (h.z == 0.f) continue;
+        AdamP a;
+        a.lr = h.x; a.wd = h.y; a.bc1 = h.z; a.bc2_sqrt = h.w; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.gscale = gscale;
+        const size_t i = c * 256 + threadIdx.x;
+        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        adamw1(pp.x, gg.x, mm.x, vv.x, a); adamw1(pp.y, gg.y, mm.y, vv.y, a);
+        adamw1(pp.z, gg.z, mm.z, vv.z, a); adamw1(pp.w, gg.w, mm.w, vv.w, a);
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, size_t n,
                                                   float alpha) {
     const size_t n4 = n / 4;
@@ -99,6 +122,18 @@ int madm_adamw_step(float* p, const float* g, float* m, float* v, size_t n, floa
     a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     adamw_kernel<<<grid_for(n / 4), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, a);
     return madm_check_launch("adamw_kernel");
+}
+
+int madm_adamw_step_table(float* p, const float* g, float* m, float* v, size_t n, const int* chunk_tensor, const float* hyper,
+                          float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    MADM_REQUIRE(p && g && m && v && chunk_tensor && hyper && n > 0 && n % 1024 == 0, "adamw_step_table: bad args (n %% 1024)");
+    MADM_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0 &&
+                     ((uintptr_t)hyper % 16) == 0, "adamw_step_table: buffers must be 16-byte aligned");
+    const size_t nchunks = n / 1024;
+    size_t grid = nchunks < 65536 ? nchunks : 65536;
+    adamw_table_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>(p, g, m, v, nchunks, chunk_tensor, (const float4*)hyper,
+                                                                      beta1, beta2, eps, grad_scale);
+    return madm_check_launch("adamw_table_kernel");
 }
 
 int madm_ema_update(float* ema, const float* p, size_t n, float alpha, void* stream) {

@@ -16,7 +16,9 @@ from .ops import _stream, _need_cuda
 class FlatParams:
     """Parameters of ``modules`` (in ``parameters()`` order, de-duplicated) as views into one flat fp32 buffer."""
 
-    def __init__(self, params, with_grad=True):
+    def __init__(self, params, with_grad=True, align=4):
+        """``align``: every tensor starts at a multiple of ``align`` elements (4 = 16 bytes; 1024 for the per-tensor
+        hyper-parameter table of ``TableAdamW``)."""
         self.params = []
         seen = set()
         for p in params:
@@ -28,8 +30,9 @@ class FlatParams:
         offs, n = [], 0
         for p in self.params:
             offs.append(n)
-            n += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
+            n += (p.numel() + align - 1) // align * align     # keep every tensor (at least) 16-byte aligned
         self.numel = n
+        self.offsets, self.align = offs, align
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev) if with_grad else None
         with torch.no_grad():
@@ -102,7 +105,7 @@ class EmaPairs:
             if spans:
                 lt, ls, lb = spans[-1]
                 gap = tp - (lt + lb)
-                if 0 <= gap < 16 and sp - (ls + lb) == gap and (lb + gap) % 4 == 0:
+                if 0 <= gap < 4096 and sp - (ls + lb) == gap and (lb + gap) % 4 == 0:   # same (zero) padding on both sides
                     spans[-1][2] = lb + gap + nb
                     continue
             spans.append([tp, sp, nb])
@@ -116,3 +119,87 @@ class EmaPairs:
             check(lib.madm_ema_update(ctypes.c_void_p(tp), ctypes.c_void_p(sp), nb // 4, float(alpha), _stream()),
                   "madm_ema_update")
         torch.autograd.graph.increment_version([t for t, _ in self.pairs])
+
+
+def default_optimizer_params(model, lr, weight_decay, weight_decay_norm=0.0, weight_decay_bias=0.0, unet_lr=None):
+    """get_default_optimizer_params_unet (utils/parameter_count.py:120-215) as used by config_files/common/optim.py:8-17:
+    one (parameter, lr, weight_decay) triple per trainable parameter in ``named_modules`` order, de-duplicated; parameters
+    of normalisation modules get ``weight_decay_norm``, parameters NAMED 'bias' get ``weight_decay_bias`` (the override
+    wins, as there), modules whose name contains 'unet' get ``unet_lr``."""
+    from . import nn as mnn
+    from . import head as mhead
+    norm_types = (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.BatchNorm3d, torch.nn.SyncBatchNorm, torch.nn.GroupNorm,
+                  torch.nn.InstanceNorm1d, torch.nn.InstanceNorm2d, torch.nn.InstanceNorm3d, torch.nn.LayerNorm,
+                  torch.nn.LocalResponseNorm, mnn.GroupNorm, mnn.LayerNorm, mhead._BN)
+    out, memo = [], set()
+    for module_name, module in model.named_modules():
+        for pname, p in module.named_parameters(recurse=False):
+            if not p.requires_grad or id(p) in memo:
+                continue
+            memo.add(id(p))
+            wd, plr = weight_decay, lr
+            if isinstance(module, norm_types) and weight_decay_norm is not None:
+                wd = weight_decay_norm
+            if 'unet' in module_name and unet_lr is not None:
+                plr = unet_lr
+            if pname == "bias" and weight_decay_bias is not None:
+                wd = weight_decay_bias
+            out.append((p, plr, wd))
+    return out
+
+
+class TableAdamW:
+    """torch.optim.AdamW over per-parameter groups (``default_optimizer_params``) as ONE launch on flat storage: every
+    tensor carries its own lr / weight decay / step count; tensors that received no gradient this step are skipped like
+    torch skips ``grad is None`` parameters.  The GradScaler unscale and the clip coefficient ride on the gradient scale."""
+
+    def __init__(self, param_table, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p, _, _ in param_table]
+        self.base_lr = [float(l) for _, l, _ in param_table]
+        self.wd = [float(w) for _, _, w in param_table]
+        self.flat = FlatParams(self.params, with_grad=True, align=1024)
+        self.betas, self.eps = betas, eps
+        self.m = torch.zeros_like(self.flat.flat)
+        self.v = torch.zeros_like(self.flat.flat)
+        self.steps = [0] * len(self.params)
+        dev = self.flat.flat.device
+        ct = torch.empty(self.flat.numel // 1024, dtype=torch.int32)
+        for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
+            ct[o // 1024:(o + (p.numel() + 1023) // 1024 * 1024) // 1024] = i
+        self.chunk_tensor = ct.to(dev)
+        self._hyper_host = torch.zeros((len(self.params), 4), dtype=torch.float32).pin_memory() if dev.type == "cuda" \
+            else torch.zeros((len(self.params), 4), dtype=torch.float32)
+        self._hyper = torch.zeros((len(self.params), 4), dtype=torch.float32, device=dev)
+        self.lr_factor = 1.0           # the LR scheduler's multiplier (WarmupParamScheduler in the reference's config)
+
+    def zero_grad(self):
+        self.flat.grad.zero_()
+
+    def step(self, clip_grad=None, loss_scale=1.0, touched=None):
+        """``touched``: ids of the parameters that received a gradient (None: all).  Returns (total gradient norm or None,
+        stepped: False when the norm is not finite -- GradScaler's inf / nan skip)."""
+        g = self.flat.grad
+        scale = 1.0 / loss_scale
+        norm = float(grad_sumsq(g).item()) ** 0.5 * scale       # one host sync (GradScaler.step syncs on found_inf too)
+        if not (norm == norm and norm != float("inf")):
+            return norm, False
+        if clip_grad is not None:
+            scale *= min(1.0, clip_grad / (norm + 1e-6))
+        h = self._hyper_host
+        b1, b2 = self.betas
+        for i, p in enumerate(self.params):
+            if touched is not None and id(p) not in touched:
+                h[i, 2] = 0.0
+                continue
+            self.steps[i] += 1
+            t = self.steps[i]
+            h[i, 0] = self.base_lr[i] * self.lr_factor
+            h[i, 1] = self.wd[i]
+            h[i, 2] = 1.0 - b1 ** t
+            h[i, 3] = (1.0 - b2 ** t) ** 0.5
+        self._hyper.copy_(h, non_blocking=True)
+        check(lib.madm_adamw_step_table(self.flat.flat.data_ptr(), g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                        self.flat.numel, self.chunk_tensor.data_ptr(), self._hyper.data_ptr(), b1, b2, self.eps,
+                                        scale, _stream()), "madm_adamw_step_table")
+        torch.autograd.graph.increment_version(self.flat.params)
+        return norm, True

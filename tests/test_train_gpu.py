@@ -248,26 +248,30 @@ def test_train_step_matches_fixture(cuda, dtype):
     assert not missing, missing[:5]
     extra = [n for n, p in params.items() if p.requires_grad and p.grad is not None and n not in set(names)]
     assert not extra, extra[:5]
-    worst = (0.0, "")
-    gtol = 1e-3 if f32 else (6e-2 if dtype == torch.float16 else 3e-1)
+    # |g| must agree to ntol; the probe dot product differs by e . probe with standard deviation |e| (e = the error vector),
+    # so |dot - dot_ref| / |g_ref| estimates the RELATIVE L2 ERROR of the whole tensor: bounded by ptol.  f32 mode: the
+    # forward is exact to ~1e-6, the gradients carry the flips of ReLU / |.| kinks at |x| ~ 1e-7 through ~250 layers.
+    ntol, ptol = {torch.float32: (1e-3, 3e-3), torch.float16: (3e-2, 8e-2), torch.bfloat16: (2e-1, 4e-1)}[dtype]
+    errs = []
     for n, (norm, dot) in zip(names, rows):
         g = params[n].grad.detach().double().cpu()
         gn = g.norm().item()
         gd = (g * grad_probe(n, g.shape).double()).sum().item()
-        scale = max(norm, 1e-12)
-        # a probe dot product has standard deviation ~ |g|: compare both on the scale of the gradient's norm
-        err = max(abs(gn - norm), abs(gd - dot)) / scale
         if norm < 1e-9:
             assert gn < 1e-6, (n, gn)
             continue
-        if err > worst[0]:
-            worst = (err, n)
-        assert err < gtol, (n, gn, norm, gd, dot)
-    print(dtype, "worst gradient checksum error", worst)
+        errs.append((abs(gn - norm) / norm, abs(gd - dot) / norm, n))
+    worst_n = max(errs, key=lambda e: e[0])
+    worst_p = max(errs, key=lambda e: e[1])
+    med_p = sorted(e[1] for e in errs)[len(errs) // 2]
+    print(dtype, f"{len(errs)} gradient tensors: worst |g| error {worst_n[0]:.2e} ({worst_n[2]}), worst probe error "
+                 f"{worst_p[1]:.2e} ({worst_p[2]}), median probe error {med_p:.2e}")
+    bad = [e for e in errs if e[0] > ntol or e[1] > ptol]
+    assert not bad, sorted(bad, key=lambda e: -e[1])[:8]
     for k in z.files:
         if k.startswith("grad:"):
             e = rel_err(params[k[5:]].grad.cpu(), torch.from_numpy(z[k]))[0]
-            assert e < (1e-3 if f32 else (8e-2 if dtype == torch.float16 else 4e-1)), (k, e)
+            assert e < (3e-3 if f32 else (8e-2 if dtype == torch.float16 else 4e-1)), (k, e)
         if k.startswith("bn:") and f32:
             _, tag, bname = k.split(":", 2)
             head = model.sem_seg_head if tag == "student" else model.ema_sem_seg_head
