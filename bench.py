@@ -52,9 +52,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lora", action="store_true", help="enable one r=8 LoRA adapter (north_star variant)")
-    ap.add_argument("--workload", default="extract", choices=["extract", "eval"],
+    ap.add_argument("--workload", default="extract", choices=["extract", "eval", "train"],
                     help="extract = BASELINE configs[1] (the metric); eval = configs[2]: full meta-arch inference "
-                         "(VAE decoder + projections + DAFormer head, RGB->Depth config, batch 1) -- informational")
+                         "(VAE decoder + projections + DAFormer head, RGB->Depth config, batch 1); train = configs[3]: one "
+                         "MTMADISE training step (source + target + teacher pass, backward, clip, AdamW, EMA), RGB->Depth "
+                         "config, full UNet fine-tune -- both informational")
+    ap.add_argument("--color-aug", action="store_true", help="train workload: colour jitter + blur of strong_transform")
     return ap.parse_args()
 
 
@@ -65,7 +68,7 @@ def make_inputs(B, size, device):
             "cond_emb": torch.zeros((B, 1, 1280), device=device)}
 
 
-def build_eval_model(dtype, device):
+def build_eval_model(dtype, device, finetune_unet='no'):
     """BASELINE configs[2]: the shipped RGB->Depth inference graph (mtmadise_cityscapes_rgb_to_depth_11.py)."""
     from madm_amd.ldm_rocm import LdmRocm
     from madm_amd.backbone import BasePromptTimeGenerator, AttentionFeatureExtractorBackbone
@@ -73,7 +76,7 @@ def build_eval_model(dtype, device):
     from madm_amd.meta_arch import MadmInference
     from madm_amd import weights
     ldm = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=(),
-                  input_range='-1+1', unet_block_indices_type='after', finetune_unet='no', compute_dtype=dtype,
+                  input_range='-1+1', unet_block_indices_type='after', finetune_unet=finetune_unet, compute_dtype=dtype,
                   weights='synthetic', seed=0, vae_decoder_loss=True, device=device)
     gen = BasePromptTimeGenerator(learnable_cond_prompt=True, learnable_cond_time=True, clip_state='no', num_timesteps=1,
                                   ldm_extractor=ldm, same_cond_params=True)
@@ -89,6 +92,74 @@ def build_eval_model(dtype, device):
         weights.synth_init_(mod, 0, prefix)
         weights.synth_buffers_(mod, 0, prefix)
     return MadmInference(backbone.to(device), head.to(device), target_modality="Depth").eval()
+
+
+def build_train_model(dtype, device, color_aug):
+    """BASELINE configs[3]: the shipped RGB->Depth training graph (mtmadise_cityscapes_rgb_to_depth_11.py: no LoRA,
+    finetune_unet='all', vae_decoder_loss 'st' / L1, reg_uncertain, rev_noise_sup + gradually, timestep range [60, 61])."""
+    from madm_amd.mtmadise import MTMADISE
+    from madm_amd.criterion import CmdiseCriterion
+    ev = build_eval_model(dtype, device, finetune_unet='all')
+    palette = [int(v) for v in torch.randint(0, 256, (33,), generator=torch.Generator().manual_seed(99))]
+    model = MTMADISE(ev.backbone, ev.sem_seg_head, CmdiseCriterion(num_classes=11), target_modality="Depth",
+                     train_palette=palette, vae_decoder_loss='st', vae_decoder_loss_type='L1',
+                     vae_decoder_loss_weight=[1.0, 1.0], reg_uncertain=True, rev_noise_sup=True, rev_noise_end_iter=5000,
+                     rev_noise_gradually=True, denoise_timestep_range=[60, 61], max_iter=10000, color_aug_flag=color_aug)
+    return model.train()
+
+
+def train_inputs(B, size, device):
+    g = torch.Generator().manual_seed(8899)
+    out = []
+    for _ in range(B):
+        lab = torch.randint(0, 11, (1, size // 16, size // 16), generator=g).repeat_interleave(16, 1).repeat_interleave(16, 2)
+        lab[torch.rand((1, size, size), generator=g) < 0.06] = 255
+        out.append({"source_rgb": (255.0 * torch.rand((3, size, size), generator=g)).to(device),
+                    "source_label": lab.long().to(device),
+                    "target_second_modality": (255.0 * torch.rand((3, size, size), generator=g)).to(device),
+                    "width": size, "height": size})
+    return out
+
+
+def run_train(args, rank, world, device, dist, mdist):
+    """configs[3]: K optimisation steps of MadmTrainer (eager launches; nothing is graph-captured yet)."""
+    from madm_amd.train import MadmTrainer
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    model = build_train_model(dtype, device, args.color_aug)
+    trainer = MadmTrainer(model, lr=5e-6, weight_decay=0.05, grad_clip=0.01, dist=dist, amp=True)
+    data = train_inputs(args.batch, args.size, device)
+    for _ in range(max(1, args.warmup)):
+        losses, norm, stepped = trainer.run_step(data)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses, norm, stepped = trainer.run_step(data)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        elapsed = mdist.max_over_ranks(elapsed, dist, device)
+    if rank == 0:
+        n_param = sum(p.numel() for p in trainer.opt.params)
+        out = {"metric": "MADM training step images/sec @512x512 bs=2/GPU (configs[3], informational)",
+               "value": round(args.batch * world * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world,
+               "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "configs[3]: MTMADISE training step, RGB->Depth config (source + mixed-target gradient "
+                                      "passes, EMA-teacher pass, 2 colour-label VAE encodes, CE + L1 losses, backward, "
+                                      f"clip 0.01, AdamW, EMA), {args.batch}x3x{args.size}x{args.size} per GPU, full UNet fine-tune "
+                                      f"({n_param / 1e6:.1f} M trainable parameters), colour augmentation "
+                                      + ("on" if args.color_aug else "off"),
+                          "global_batch": args.batch * world,
+                          "parallelism": f"dp{world}: gradient all-reduce(mean) over the flat fp32 buffer" if world > 1 else "dp1",
+                          "launch": "eager"},
+               "last_losses": losses, "grad_norm": norm, "stepped": stepped, "loss_scale": trainer.scale,
+               "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def kernel_profile(model, inputs):
@@ -192,6 +263,8 @@ def main():
 
     from madm_amd.ldm_rocm import LdmRocm
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    if args.workload == "train":
+        return run_train(args, rank, world, device, dist, mdist)
     if args.workload == "eval":
         args.batch = 1
         model = build_eval_model(dtype, device)

@@ -71,7 +71,8 @@ def pseudo_labels(ema_logits, size, pseudo_threshold):
     count = torch.zeros(1, dtype=torch.int64, device=x.device)
     ops.check(lib.madm_pseudo_label(x.data_ptr(), prob.data_ptr(), label.data_ptr(), count.data_ptr(), B, K, H * W,
                                     float(pseudo_threshold), _s()), "madm_pseudo_label")
-    pseudo_val = count.to(torch.float32) / float(B * H * W)          # stays on the device
+    # python float64 division in the reference (torch.sum(...).item() / ps_size), then a float32 tensor: the same rounding
+    pseudo_val = (count.to(torch.float64) / float(B * H * W)).to(torch.float32)          # stays on the device
     pseudo_weight = pseudo_val * torch.ones(prob.shape, device=x.device)
     return prob, label, pseudo_weight
 

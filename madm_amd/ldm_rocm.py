@@ -278,14 +278,40 @@ class LdmRocm(nn.Module):
             self.exclude_unused_params()
 
     def exclude_unused_params(self):
-        """ldm_diffusers.py:123-141 discovers by a dummy backward which UNet parameters feed the last tap.
-        With taps 'after' the last up-block resnet/attention, those are exactly conv_norm_out / conv_out."""
-        last = max(self.unet_block_indices) if len(self.unet_block_indices) else -1
-        n_res = sum(len(b.resnets) for b in self.unet.up_blocks)
-        if last == n_res - 1 or last == -1:
-            for m in (self.unet.conv_norm_out, self.unet.conv_out):
-                for p in m.parameters():
-                    p.requires_grad = False
+        """ldm_diffusers.py:123-141 runs a dummy forward / backward from ``unet_features[-1]`` and freezes every UNet
+        parameter that received no gradient (DDP runs with find_unused_parameters=False, config_files/common/train.py:12).
+        The same set, derived from the graph instead of a probe run: in forward order everything AFTER the last tap --
+        up-block resnets / attentions whose flat index lies behind it ('in' taps: the tapped resnet itself too, the tap is
+        its concatenated INPUT, :372-375,411-414), an up block's upsampler unless a later block still feeds the tap, and
+        always conv_norm_out / conv_out (tests/test_bridge.py checks this against the reference's procedure)."""
+        if not len(self.unet_block_indices):
+            unused = [self.unet.conv_norm_out, self.unet.conv_out]
+        else:
+            last = max(self.unet_block_indices)            # taps are appended in forward order: [-1] is the largest index
+            after = self.unet_block_indices_type == 'after'
+            unused = [self.unet.conv_norm_out, self.unet.conv_out]
+            idx = 0
+            blocks = list(self.unet.up_blocks)
+            first_idx = []
+            for blk in blocks:
+                first_idx.append(idx)
+                for i, r in enumerate(blk.resnets):
+                    used = idx <= last if after else idx < last
+                    if not used:
+                        unused.append(r)
+                        if blk.has_cross_attention:
+                            unused.append(blk.attentions[i])
+                    idx += 1
+            for k, blk in enumerate(blocks):
+                if blk.upsamplers is None:
+                    continue
+                nxt = first_idx[k + 1] if k + 1 < len(blocks) else idx
+                feeds = nxt <= last   # 'after': the next block's first resnet is used; 'in': the tap is (at or behind) its input
+                if k + 1 >= len(blocks) or not feeds:
+                    unused.extend(blk.upsamplers)
+        for m in unused:
+            for p in m.parameters():
+                p.requires_grad = False
 
     def _get_uncond_inputs(self, text):
         """ldm_diffusers.py:219-243 runs the CLIP text encoder on '' once at construction.  The text
@@ -481,7 +507,7 @@ class _UNetTapsFn(torch.autograd.Function):
         dtaps = [tokens(gouts[i]) for i in range(n_taps)]   # autograd materialises zeros for unused outputs
         dsample = None
         if k["with_sample"] and gouts[n_taps] is not None:
-            dsample = tokens(gouts[n_taps], cpad=unet.conv_out.n_pad)
+            dsample = tokens(gouts[n_taps], cpad=max(unet.conv_out.n_pad, 16 // torch.empty(0, dtype=dtype).element_size()))
         names = k["param_names"]
         base = any(".lora_" not in n for n in names)
         res = bw.unet_backward_from_state(k.pop("state"), dtaps, dsample=dsample, base_grads=base)

@@ -322,7 +322,7 @@ class MTMADISE(MadmInference):
             dtaps.append(d if d.shape[1] == tk.C else d[:, :tk.C].contiguous())
         ds = None
         if dsample is not None:
-            ds = ops.nchw_to_nhwc(dsample.float().contiguous(), dtype, unet.conv_out.n_pad)
+            ds = ops.nchw_to_nhwc(dsample.float().contiguous(), dtype, max(unet.conv_out.n_pad, 16 // dsample.new_empty(0, dtype=dtype).element_size()))
         up = dict(unet.named_parameters())
         base = any(p.requires_grad and ".lora_" not in n for n, p in up.items())
         res = bw.unet_backward_from_state(state, dtaps, dsample=ds, base_grads=base)
@@ -376,4 +376,5 @@ class _TrainStepFn(torch.autograd.Function):
                 continue
             model._backward_pass(rec, dlogits, dsample, add)
         st["rec_s"] = st["rec_t"] = None       # free the tapes
+        model.last_grad_param_ids = set(acc.keys())    # torch.optim.AdamW skips parameters whose grad is None
         return (None, None) + (None,) * ctx.n_losses + tuple(acc.get(id(p)) for p in params)

@@ -1,16 +1,15 @@
-"""One optimisation step of the LdmRocm extractor with a torch-side loss (the reference's step is
-engine/train_loop.py:203-217 -- backward, unscale, clip_grad_norm_, optimizer.step -- plus CMDISE._update_ema,
-modeling/meta_arch/cmdise.py:337-349):
+"""Training loop pieces around ``MTMADISE`` (BASELINE config 4): the reference's ``AMPTrainer.run_step``
+(/root/reference/engine/train_loop.py:257-311) -- autocast forward, ``model.zero_grad()``, ``scaler.scale(losses)
+.backward()``, unscale, ``clip_grad_norm_``, ``optimizer.step()``, ``scaler.update()`` -- on flat storage:
 
-    feats = ldm(batch)                 HIP forward (no-grad) + ONE autograd node over the UNet stage
-    loss  = loss_fn(feats)             torch: whatever consumes the features (projections / head / criterion)
-    loss.backward()                    torch autograd -> _UNetTapsFn.backward -> backward.unet_backward (HIP kernels);
-                                       gradients accumulate straight into the flat fp32 gradient buffer
-    all-reduce(mean)                   dist.GradBucketReducer over that buffer (multi-GPU only)
-    clip + AdamW, EMA                  optim.FlatAdamW / optim.ema_update: three launches over the flat buffers
+    losses = model(data)                      HIP forward (3 passes), loss scalars = outputs of ONE autograd node
+    (scale * sum(losses)).backward()          explicit HIP backward; gradients accumulate into ONE flat fp32 buffer
+    all-reduce(mean)                          dist.GradBucketReducer over that buffer (DDP's only job; world > 1)
+    clip + AdamW                              optim.TableAdamW: ONE launch, per-tensor lr / weight decay / step
+                                              (get_default_optimizer_params_unet: no decay on norms and biases, unet_lr)
+    GradScaler bookkeeping                    dynamic loss scale (fp16 compute mode), inf / nan steps skipped
 
-The trainable set is whatever has requires_grad on the UNet (``LdmRocm._freeze`` modes, or the active LoRA matrices)
-plus ``extra_params`` (e.g. the prompt / time embeddings of BasePromptTimeGenerator, ldm_base.py:632-717).
+``ExtractorTrainer`` (round 1) trains the extractor alone against a caller-supplied torch loss and is kept for that use.
 """
 import torch
 
@@ -18,7 +17,62 @@ from . import optim
 from .dist import GradBucketReducer
 
 
+class MadmTrainer:
+    """One process per GPU.  ``dist``: an initialised torch.distributed module (backend nccl == RCCL, or gloo) or None.
+    At construction rank 0's parameters are broadcast (DistributedDataParallel's start-up contract, main.py:289-294)."""
+
+    def __init__(self, model, lr, weight_decay, grad_clip=None, unet_lr=None, betas=(0.9, 0.999), eps=1e-8, dist=None,
+                 amp=True, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
+                 lr_multiplier=None):
+        self.model = model
+        table = optim.default_optimizer_params(model, lr, weight_decay, weight_decay_norm=0.0, weight_decay_bias=0.0,
+                                               unet_lr=unet_lr)
+        assert table, "nothing to train"
+        self.opt = optim.TableAdamW(table, betas=betas, eps=eps)
+        self.grad_clip = grad_clip
+        self.dist = dist
+        self.reducer = GradBucketReducer(self.opt.flat.grad, dist)
+        if dist is not None and dist.get_world_size() > 1:
+            dist.broadcast(self.opt.flat.flat, src=0)
+            torch.autograd.graph.increment_version(self.opt.flat.params)
+            for b in model.buffers():               # DDP broadcasts buffers too (BatchNorm running statistics)
+                dist.broadcast(b, src=0)
+        # torch.cuda.amp.GradScaler semantics (only needed for the fp16 compute mode; harmless otherwise)
+        self.scale = float(init_scale) if amp else 1.0
+        self.amp, self.growth_factor, self.backoff_factor, self.growth_interval = amp, growth_factor, backoff_factor, growth_interval
+        self._growth_tracker = 0
+        self.lr_multiplier = lr_multiplier          # callable(iter) -> factor (WarmupParamScheduler in the shipped config)
+        self.iter = 0
+
+    def run_step(self, data):
+        """Returns (loss dict of python floats, total gradient norm, stepped)."""
+        model = self.model
+        assert model.training, "[MadmTrainer] model was changed to eval mode!"
+        self.opt.zero_grad()
+        loss_dict = model(data)
+        losses = sum(loss_dict.values())
+        (losses * self.scale).backward()
+        self.reducer.finish()
+        if self.lr_multiplier is not None:
+            self.opt.lr_factor = float(self.lr_multiplier(self.iter))
+        touched = getattr(model, "last_grad_param_ids", None)
+        norm, stepped = self.opt.step(clip_grad=self.grad_clip, loss_scale=self.scale, touched=touched)
+        if self.amp:
+            if not stepped:
+                self.scale *= self.backoff_factor
+                self._growth_tracker = 0
+            else:
+                self._growth_tracker += 1
+                if self._growth_tracker == self.growth_interval:
+                    self.scale *= self.growth_factor
+                    self._growth_tracker = 0
+        self.iter += 1
+        return {k: float(v.detach()) for k, v in loss_dict.items()}, norm, stepped
+
+
 class ExtractorTrainer:
+    """One optimisation step of the LdmRocm extractor alone with a torch-side loss on its features (round-1 slice)."""
+
     def __init__(self, ldm, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, clip_grad=None, dist=None,
                  ema_alpha=None, extra_params=()):
         self.ldm = ldm
@@ -30,6 +84,7 @@ class ExtractorTrainer:
         self.reducer = GradBucketReducer(self.flat.grad, dist)
         self.ema_alpha = ema_alpha
         self.ema = self.flat.flat.clone() if ema_alpha is not None else None
+        self.iter = 0
 
     def step(self, batched_inputs, loss_fn, input_modal="rgb", **kwargs):
         """Returns (loss value as a python float, total gradient norm or None)."""
@@ -39,6 +94,7 @@ class ExtractorTrainer:
         loss.backward()
         self.reducer.finish()
         norm = self.opt.step(clip_grad=self.clip_grad)
-        if self.ema is not None:
-            optim.ema_update(self.ema, self.flat.flat, self.ema_alpha)
+        if self.ema is not None:   # CMDISE._update_ema: alpha_teacher = min(1 - 1 / (iter + 1), ema_alpha) (cmdise.py:337-338)
+            self.iter += 1
+            optim.ema_update(self.ema, self.flat.flat, min(1 - 1 / (self.iter + 1), self.ema_alpha))
         return float(loss.detach()), norm
