@@ -482,6 +482,16 @@ int madm_softmax_ce(int dtype, const float* logits, int ldx, int K, const int64_
  *   dpred (NULL = skip) = coef * (*gscale) * mask * sign(pred - gt)  (or 2 (pred - gt)). */
 int madm_masked_l1(const float* pred, const float* gt, const float* mask, int B, int C, int h, int w, int Hm, int Wm, int l2,
                    double* loss_sum, const float* gscale, float coef, float* dpred, void* stream);
+/* strong_transform's colour augmentation of the mixed / target image (utils/dacs_transforms.py:40-78; kornia
+ * ColorJitter + GaussianBlur2d, un-vendored and unpinned -- restated in oracle/augment.py) on ONE RGB image [3][HW] f32 in
+ * [0, 1]: madm_gray_sum adds sum(0.299 r + 0.587 g + 0.114 b) into *out (f64); madm_color_jitter_step applies one of
+ * 0 brightness (x f), 1 contrast (x f + mean_gray (1 - f), mean from *gray_sum / HW), 2 saturation ((1 - f) gray + f x),
+ * 3 hue (HSV rotation by f radians); madm_blur_axis_f32 is one pass of the separable Gaussian blur (reflect border) along
+ * axis 0 (y) or 1 (x) with `ksize` device weights. */
+int madm_gray_sum(const float* img, size_t HW, double* out, void* stream);
+int madm_color_jitter_step(const float* in, float* out, size_t HW, int op, float factor, const double* gray_sum, void* stream);
+int madm_blur_axis_f32(const float* in, float* out, int planes, int H, int W, int axis, int ksize, const float* weights,
+                       void* stream);
 /* backward of madm_tanh_gate for dout [repeat][n]: with g_i = sum_r dout[r][i], dx1 += tanh(a1) g, da1 += (1 - tanh^2(a1))
  * x1 g and likewise for (a2, x2); every output is ACCUMULATED into and may be NULL. */
 int madm_tanh_gate_bwd(const float* a1, const float* x1, const float* a2, const float* x2, const float* dout, float* da1,

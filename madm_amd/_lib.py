@@ -182,6 +182,9 @@ SYMBOLS = [
                                 c_float, c_void_p, c_int, c_void_p]),
     ("madm_masked_l1", c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                c_void_p, c_float, c_void_p, c_void_p]),
+    ("madm_gray_sum", c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    ("madm_color_jitter_step", c_int, [c_void_p, c_void_p, c_size_t, c_int, c_float, c_void_p, c_void_p]),
+    ("madm_blur_axis_f32", c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("madm_tanh_gate_bwd", c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_size_t, c_int, c_void_p]),
 ]

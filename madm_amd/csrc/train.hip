@@ -285,6 +285,87 @@ __global__ void bn_fold_stats_kernel(const double* __restrict__ in, int B, int C
     }
 }
 
+// ---- colour augmentation of strong_transform (utils/dacs_transforms.py:40-78 -> kornia ColorJitter / GaussianBlur2d) ----
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+__device__ __forceinline__ float gray_of(float r, float g, float b) { return 0.299f * r + 0.587f * g + 0.114f * b; }
+
+// *out (f64, zeroed) += sum over pixels of the grey value of one RGB image [3][HW]
+__global__ __launch_bounds__(256) void gray_sum_kernel(const float* __restrict__ img, size_t HW, double* out) {
+    __shared__ double red[4];
+    double local = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (size_t)gridDim.x * blockDim.x)
+        local += (double)gray_of(img[i], img[HW + i], img[2 * HW + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// one step of kornia's ColorJitter on one RGB image [3][HW] in [0, 1] (in place allowed):
+//   op 0 brightness: x * f;  1 contrast: x * f + mean_gray * (1 - f);  2 saturation: (1 - f) * gray + f * x;
+//   3 hue: rgb -> hsv, h = fmod(h + f, 2 pi), hsv -> rgb.   Ops 0-2 clamp to [0, 1].
+__global__ __launch_bounds__(256) void color_jitter_kernel(const float* __restrict__ in, float* __restrict__ out, size_t HW,
+                                                           int op, float f, const double* __restrict__ gray_sum) {
+    const float mean = (op == 1) ? (float)(gray_sum[0] / (double)HW) : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (size_t)gridDim.x * blockDim.x) {
+        float r = in[i], g = in[HW + i], b = in[2 * HW + i];
+        if (op == 0) {
+            r = clamp01(r * f); g = clamp01(g * f); b = clamp01(b * f);
+        } else if (op == 1) {
+            const float m = mean * (1.f - f);
+            r = clamp01(r * f + m); g = clamp01(g * f + m); b = clamp01(b * f + m);
+        } else if (op == 2) {
+            const float y = (1.f - f) * gray_of(r, g, b);
+            r = clamp01(y + f * r); g = clamp01(y + f * g); b = clamp01(y + f * b);
+        } else {
+            const float TWO_PI = 6.283185307179586f;
+            const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));
+            float dc = mx - mn;
+            const float v = mx, s = dc / (mx + 1e-8f);
+            if (dc == 0.f) dc = 1.f;
+            const float rc = mx - r, gc = mx - g, bc = mx - b;
+            float h = (r == mx) ? (bc - gc) : ((g == mx) ? (rc - bc) + 2.f * dc : (gc - rc) + 4.f * dc);   // first maximum wins
+            h = h / dc / 6.f;
+            h = h - floorf(h);                                   // python-style % 1.0
+            h = fmodf(TWO_PI * h + f, TWO_PI);                   // torch.fmod keeps the sign of the dividend
+            const float h6 = h / TWO_PI * 6.f;
+            float hi = floorf(h6);
+            hi = hi - 6.f * floorf(hi / 6.f);                    // % 6
+            float ff = h6 - 6.f * floorf(h6 / 6.f) - hi;
+            const float p = v * (1.f - s), q = v * (1.f - ff * s), t = v * (1.f - (1.f - ff) * s);
+            const int k = (int)hi;
+            r = (k == 0 || k == 5) ? v : ((k == 1) ? q : ((k == 4) ? t : p));
+            g = (k == 1 || k == 2) ? v : ((k == 0) ? t : ((k == 3) ? q : p));
+            b = (k == 3 || k == 4) ? v : ((k == 2) ? t : ((k == 5) ? q : p));
+        }
+        out[i] = r; out[HW + i] = g; out[2 * HW + i] = b;
+    }
+}
+
+// 1-D correlation along x (axis 1) or y (axis 0) of `planes` f32 planes [H][W] with `ks` weights, reflect border
+// (kornia filter2d_separable(border_type='reflect')).
+__global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out, int planes,
+                                                        int H, int W, int axis, int ks, const float* __restrict__ wts) {
+    const size_t total = (size_t)planes * H * W;
+    const int half = ks / 2, L = axis ? W : H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const size_t t = i / W;
+        const int y = (int)(t % H);
+        const float* pl = in + (t / H) * (size_t)H * W;
+        const int c0 = axis ? x : y;
+        float acc = 0.f;
+        for (int k = 0; k < ks; ++k) {
+            int c = c0 + k - half;
+            if (c < 0) c = -c;
+            if (c >= L) c = 2 * (L - 1) - c;
+            acc += wts[k] * (axis ? pl[(size_t)y * W + c] : pl[(size_t)c * W + x]);
+        }
+        out[i] = acc;
+    }
+}
+
 unsigned grid_for(size_t n, unsigned cap = 8192) {
     size_t g = (n + 255) / 256;
     if (g > cap) g = cap;
@@ -387,6 +468,26 @@ int madm_masked_l1(const float* pred, const float* gt, const float* mask, int B,
     masked_l1_kernel<<<grid_for((size_t)B * C * h * w, 1024), 256, 0, (hipStream_t)stream>>>(pred, gt, mask, B, C, h, w, Hm, Wm,
                                                                                             l2, loss_sum, gscale, coef, dpred);
     return madm_check_launch("masked_l1_kernel");
+}
+
+int madm_gray_sum(const float* img, size_t HW, double* out, void* stream) {
+    MADM_REQUIRE(img && out && HW > 0, "gray_sum: bad argument");
+    gray_sum_kernel<<<grid_for(HW, 256), 256, 0, (hipStream_t)stream>>>(img, HW, out);
+    return madm_check_launch("gray_sum_kernel");
+}
+
+int madm_color_jitter_step(const float* in, float* out, size_t HW, int op, float factor, const double* gray_sum, void* stream) {
+    MADM_REQUIRE(in && out && HW > 0 && op >= 0 && op <= 3 && (op != 1 || gray_sum), "color_jitter_step: bad argument");
+    color_jitter_kernel<<<grid_for(HW, 2048), 256, 0, (hipStream_t)stream>>>(in, out, HW, op, factor, gray_sum);
+    return madm_check_launch("color_jitter_kernel");
+}
+
+int madm_blur_axis_f32(const float* in, float* out, int planes, int H, int W, int axis, int ksize, const float* weights,
+                       void* stream) {
+    MADM_REQUIRE(in && out && weights && in != out && planes > 0 && H > 0 && W > 0 && (axis == 0 || axis == 1) && ksize > 0 &&
+                     ksize / 2 < (axis ? W : H), "blur_axis: bad argument");
+    blur_axis_kernel<<<grid_for((size_t)planes * H * W), 256, 0, (hipStream_t)stream>>>(in, out, planes, H, W, axis, ksize, weights);
+    return madm_check_launch("blur_axis_kernel");
 }
 
 int madm_tanh_gate_bwd(const float* a1, const float* x1, const float* a2, const float* x2, const float* dout, float* da1,

@@ -147,7 +147,7 @@ class Conv2d(_Packed):
         wp, b = self.packed(dtype, splits)
         OH, OW = self.out_hw(x.H, x.W, upsample)
         pad = 0 if self.asym_pad else self.padding
-        st = ops.new_chsums(x.B, self.n_pad, x.t.device) if stats else None
+        st = ops.new_chsums(x.B, self.n_pad, x.t.device) if (stats and not ops.EXP_NO_STATS) else None
         o = ops.conv2d(x.t, wp, x.B, x.H, x.W, N=self.n_pad, x2=None if x2 is None else x2.t,
                        KH=self.kernel_size, KW=self.kernel_size, stride=self.stride, pad_t=pad, pad_l=pad,
                        OH=OH, OW=OW, upsample=upsample, bias=b, rowvec=rowvec,

@@ -287,3 +287,31 @@ def test_train_step_matches_fixture(cuda, dtype):
             _, tag, bname = k.split(":", 2)
             head = model.sem_seg_head if tag == "student" else model.ema_sem_seg_head
             assert rel_err(dict(head.named_buffers())[bname].cpu(), torch.from_numpy(z[k]))[0] < 1e-4, k
+
+
+def test_color_augmentation_kernels(cuda):
+    """strong_transform's colour jitter + Gaussian blur (dacs_transforms.py:40-78) vs the kornia restatement in
+    oracle/augment.py (parity unpinned by the reference: kornia is neither vendored nor pinned)."""
+    from madm_amd import augment
+    from oracle import augment as OA
+    g = torch.Generator().manual_seed(31)
+    img = torch.rand((3, 48, 80), generator=g)
+    img[:, 5, 5] = 0.3                                    # a grey pixel (zero chroma) and saturated ones
+    img[:, 6, 6] = torch.tensor([1.0, 0.0, 0.0])
+    for trial in range(6):
+        fb, fc, fh, fs, order = augment.jitter_params(0.2, generator=g)
+        assert 0.8 <= fb <= 1.2 and 0.8 <= fc <= 1.2 and -0.2 <= fh <= 0.2 and 0.8 <= fs <= 1.2 and sorted(order) == [0, 1, 2, 3]
+        got = augment.color_jitter_image(img.cuda(), fb, fc, fh, fs, order).cpu()
+        ref = OA.color_jitter_image(img, fb, fc, fh, fs, order)
+        assert (got - ref).abs().max() < 2e-5, (trial, (got - ref).abs().max())
+    data = torch.rand((2, 3, 64, 96), generator=g)
+    ky, kx = augment.blur_kernel_size(64), augment.blur_kernel_size(96)
+    assert (ky, kx) == (7, 9) and augment.blur_kernel_size(512) == 51
+    got = augment.gaussian_blur(data.cuda(), 0.7).cpu()
+    assert (got - OA.gaussian_blur(data, ky, kx, 0.7)).abs().max() < 1e-6
+    # the branch conditions of strong_transform
+    p = {'color_jitter': 0.1, 'color_jitter_s': 0.2, 'color_jitter_p': 0.2, 'blur': 0.3, 'mean': None, 'std': None}
+    assert torch.equal(augment.strong_color(p, data.cuda()).cpu(), data)
+    p.update(color_jitter=0.9, blur=0.9)
+    out = augment.strong_color(p, data.cuda(), generator=torch.Generator().manual_seed(1), rng=np.random.RandomState(2))
+    assert out.shape == data.shape and not torch.equal(out.cpu(), data) and 0 <= out.min() and out.max() <= 1
