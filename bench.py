@@ -52,9 +52,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lora", action="store_true", help="enable one r=8 LoRA adapter (north_star variant)")
-    ap.add_argument("--workload", default="extract", choices=["extract", "eval", "train"],
+    ap.add_argument("--workload", default="extract", choices=["extract", "eval", "slide", "train"],
                     help="extract = BASELINE configs[1] (the metric); eval = configs[2]: full meta-arch inference "
-                         "(VAE decoder + projections + DAFormer head, RGB->Depth config, batch 1); train = configs[3]: one "
+                         "(VAE decoder + projections + DAFormer head, RGB->Depth config, batch 1); slide = configs[4] geometry: "
+                         "the same on a 1024 x 512 image through sliding-window inference (three 512-wide windows as ONE "
+                         "batched forward, feature_extractor.py:199-278, K = 9 Infrared head); train = configs[3]: one "
                          "MTMADISE training step (source + target + teacher pass, backward, clip, AdamW, EMA), RGB->Depth "
                          "config, full UNet fine-tune -- both informational")
     ap.add_argument("--color-aug", action="store_true", help="train workload: colour jitter + blur of strong_transform")
@@ -68,7 +70,7 @@ def make_inputs(B, size, device):
             "cond_emb": torch.zeros((B, 1, 1280), device=device)}
 
 
-def build_eval_model(dtype, device, finetune_unet='no'):
+def build_eval_model(dtype, device, finetune_unet='no', slide=False, num_classes=11):
     """BASELINE configs[2]: the shipped RGB->Depth inference graph (mtmadise_cityscapes_rgb_to_depth_11.py)."""
     from madm_amd.ldm_rocm import LdmRocm
     from madm_amd.backbone import BasePromptTimeGenerator, AttentionFeatureExtractorBackbone
@@ -82,9 +84,10 @@ def build_eval_model(dtype, device, finetune_unet='no'):
                                   ldm_extractor=ldm, same_cond_params=True)
     backbone = AttentionFeatureExtractorBackbone(
         attention_features_res=None, feature_dims=[3, 320, 640, 1280], projection_dim=[128, 512, 512, 512],
-        attention_features_location=None, feature_extractor=gen, num_res_blocks=1, out_features=["s0", "s3", "s4", "s5"])
+        attention_features_location=None, feature_extractor=gen, num_res_blocks=1, out_features=["s0", "s3", "s4", "s5"],
+        slide_inference=slide)
     head = DAFormerHead(in_channels=[128, 512, 512, 512], in_keys=["s0", "s3", "s4", "s5"], in_index=[0, 1, 2, 3], channels=256,
-                        dropout_ratio=0.1, num_classes=11, norm_cfg=dict(type='BN'), align_corners=False,
+                        dropout_ratio=0.1, num_classes=num_classes, norm_cfg=dict(type='BN'), align_corners=False,
                         decoder_params=dict(embed_dims=256, embed_cfg=dict(type='mlp'), embed_neck_cfg=dict(type='mlp'),
                                             fusion_cfg=dict(type='aspp', sep=True, dilations=(1, 6, 12, 18), pool=False)))
     for prefix, mod in (("backbone.feature_projections.", backbone.feature_projections),
@@ -265,11 +268,12 @@ def main():
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     if args.workload == "train":
         return run_train(args, rank, world, device, dist, mdist)
-    if args.workload == "eval":
+    if args.workload in ("eval", "slide"):
         args.batch = 1
-        model = build_eval_model(dtype, device)
+        slide = args.workload == "slide"
+        model = build_eval_model(dtype, device, slide=slide, num_classes=9 if slide else 11)
         ldm = model.backbone.feature_extractor.ldm_extractor
-        call = ([{"target_second_modality": 255.0 * torch.rand((3, args.size, args.size),
+        call = ([{"target_second_modality": 255.0 * torch.rand((3, args.size, args.size * (2 if slide else 1)),
                                                                 generator=torch.Generator().manual_seed(777)).to(device)}],)
         return run(args, model, call, ldm, rank, world, device, dist, mdist)
     model = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=[],
@@ -384,10 +388,15 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
         images = args.batch * world * args.steps
         value = images / elapsed
         peak = PEAK_BF16_TFLOPS if args.dtype in ("bf16", "f16") else PEAK_F32_TFLOPS
-        alg = ALG_FLOP_PER_IMAGE if args.workload == "extract" else 6.34725e12   # full eval forward
+        # full eval forward 6 347.25 GFLOP per 512 x 512 image; sliding windows: 3 x (extractor + decoder +
+        # projections) + the head on the 512 x 1024 canvas (2 x 1 821.27)
+        alg = {"extract": ALG_FLOP_PER_IMAGE, "eval": 6.34725e12,
+               "slide": 3 * (1.91993e12 + 2.51452e12 + 0.09153e12) + 2 * 1.82127e12}[args.workload]
         out = {
-            "metric": "UNet feature-extract images/sec @512x512 bs=2/GPU" if args.workload == "extract"
-            else "full meta-arch eval images/sec @512x512 bs=1 (configs[2], informational)",
+            "metric": {"extract": "UNet feature-extract images/sec @512x512 bs=2/GPU",
+                       "eval": "full meta-arch eval images/sec @512x512 bs=1 (configs[2], informational)",
+                       "slide": "sliding-window eval images/sec @1024x512 bs=1, 3 windows (configs[4] geometry, informational)"
+                       }[args.workload],
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -396,8 +405,12 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
                                     f"(taps 5,8,11 'after'), {args.batch}x3x{args.size}x{args.size} per GPU, t=0, "
                                     "LoRA " + ("r=8 on" if args.lora else "off (shipped configs)") +
                                     ", seeded synthetic weights") if args.workload == "extract" else
-                       ("configs[2]: full MADM inference forward, RGB->Depth config (VAE enc -> UNet -> VAE dec -> "
-                        f"GN projections -> DAFormer head @512x512, K=11), 1x3x{args.size}x{args.size} per GPU"),
+                       (("configs[2]: full MADM inference forward, RGB->Depth config (VAE enc -> UNet -> VAE dec -> "
+                         f"GN projections -> DAFormer head @512x512, K=11), 1x3x{args.size}x{args.size} per GPU")
+                        if args.workload == "eval" else
+                        ("configs[4] geometry: sliding-window inference of a 1x3x512x1024 image (three 512-wide windows "
+                         "batched as B=3 through VAE enc -> UNet -> VAE dec -> projections, window features averaged, "
+                         "DAFormer head @512x1024, K=9)")),
                        "global_batch": args.batch * world, "parallelism": f"replicas x{world} (no collectives)",
                        "launch": "eager" if args.no_graph else ("hipGraph replay, 1 stream: one batch in flight"
                                                                 if args.streams <= 1 else

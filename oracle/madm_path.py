@@ -17,8 +17,14 @@ from . import sd_modules, ldm_path, third_party as tp
 DEPTH_CFG = dict(out_features=["s0", "s3", "s4", "s5"], feature_dims=[3, 320, 640, 1280],
                  projection_dim=[128, 512, 512, 512], head_in_channels=[128, 512, 512, 512], num_classes=11,
                  vae_decoder_loss=True)
+# config_files/SemSeg/MTMADISE/mtmadise_cityscapes_rgb_to_infrared_9.py: the same graph with the 9 FMB classes
+INFRARED_CFG = dict(DEPTH_CFG, num_classes=9)
 S345_CFG = dict(out_features=["s3", "s4", "s5"], feature_dims=[320, 640, 1280], projection_dim=[512, 512, 512],
                 head_in_channels=[512, 512, 512], num_classes=11, vae_decoder_loss=False)   # main.py:480-484
+
+
+def cfg_by_name(name):
+    return {"DEPTH": DEPTH_CFG, "INFRARED": INFRARED_CFG, "S345": S345_CFG}[name]
 
 
 def head_decoder_params():

@@ -209,16 +209,19 @@ class OracleMTMADISE(nn.Module):
                 _, w = OL.one_mix(mix_masks[i], target=torch.stack((gt_pixel_weight[i], pseudo_weight[i])))
                 mixed_seg_weight[i] = w
             mixed_lbl = torch.cat(mixed_lbl)
-        target_color_gt, target_color_gt_mask = OL.convert_label_to_rgb(mixed_lbl, self.reg_target_palette)
-        target_color_gt_latent = ldm_path.vae_encoder(vae, target_color_gt, [])[0]
-        target_color_gt_mask = target_color_gt_mask * pseudo_weight[:, None]
-
         loss_input = {'source_rgb_pred': source_pred, 'target_sec_modal_pred': target_pred}
-        loss_target = {'source_gt': gt, 'target_pl': mixed_lbl, 'target_pw': mixed_seg_weight, 'vae_decoder_loss': {
-            'source': {'pred': source_out['before_vae.decoder'], 'gt': source_color_gt_latent, 'mask': source_color_gt_mask,
-                       'loss_weight': self.vae_decoder_loss_weight[0], 'loss_type': self.vae_decoder_loss_type},
-            'target': {'pred': target_out['before_vae.decoder'], 'gt': target_color_gt_latent, 'mask': target_color_gt_mask,
-                       'loss_weight': self.vae_decoder_loss_weight[1], 'loss_type': self.vae_decoder_loss_type}}}
+        loss_target = {'source_gt': gt, 'target_pl': mixed_lbl, 'target_pw': mixed_seg_weight, 'vae_decoder_loss': {}}
+        if 's' in self.vae_decoder_loss:                                     # :609-616
+            loss_target['vae_decoder_loss']['source'] = {
+                'pred': source_out['before_vae.decoder'], 'gt': source_color_gt_latent, 'mask': source_color_gt_mask,
+                'loss_weight': self.vae_decoder_loss_weight[0], 'loss_type': self.vae_decoder_loss_type}
+        if 't' in self.vae_decoder_loss:                                     # :394-397, :617-624
+            target_color_gt, target_color_gt_mask = OL.convert_label_to_rgb(mixed_lbl, self.reg_target_palette)
+            target_color_gt_latent = ldm_path.vae_encoder(vae, target_color_gt, [])[0]
+            target_color_gt_mask = target_color_gt_mask * pseudo_weight[:, None]
+            loss_target['vae_decoder_loss']['target'] = {
+                'pred': target_out['before_vae.decoder'], 'gt': target_color_gt_latent, 'mask': target_color_gt_mask,
+                'loss_weight': self.vae_decoder_loss_weight[1], 'loss_type': self.vae_decoder_loss_type}
         losses = self.criterion(loss_input, loss_target)
         self.train_iter_index += 1
         self.last_step = dict(mixed_img=mixed_img, mixed_lbl=mixed_lbl, mixed_seg_weight=mixed_seg_weight,

@@ -89,7 +89,7 @@ def main_eval():
     for name, case in EVAL_CASES.items():
         if only and name not in only:
             continue
-        cfg = madm_path.DEPTH_CFG if case["cfg"] == "DEPTH" else madm_path.S345_CFG
+        cfg = madm_path.cfg_by_name(case["cfg"])
         backbone, head = madm_path.build_reference_eval_model(ns, vae, unet, cfg)
         init_eval_params(backbone, head)
         t0 = time.time()
@@ -130,16 +130,17 @@ def main_slide():
     print(f"slide_s345: {time.time() - t0:.1f}s", {k: v.shape for k, v in out.items()})
 
 
-def build_train_oracle(reference=True):
+def build_train_oracle(reference=True, variant="train_depth"):
     """OracleMTMADISE of the Depth config at TRAIN_CASE size; ``reference``: the REFERENCE's DAFormerHead class and
     CmdiseCriterion (this container), else the oracle's restatements (anywhere)."""
     from oracle import madm_path, train_path
-    from golden_util import TRAIN_CASE, train_palette, train_dropout_scales
+    from golden_util import TRAIN_CASE, TRAIN_VARIANTS, train_palette, train_dropout_scales
     cfg = madm_path.DEPTH_CFG
     vae, unet = build_oracle(lora=False)
     crit = train_path.reference_criterion() if reference else None
     model = train_path.build(vae, unet, cfg, criterion_cls=crit, in_size=TRAIN_CASE["size"],
-                             train_palette=train_palette(TRAIN_CASE["K"]), pseudo_threshold=TRAIN_CASE["pseudo_threshold"])
+                             train_palette=train_palette(TRAIN_CASE["K"]), pseudo_threshold=TRAIN_CASE["pseudo_threshold"],
+                             **TRAIN_VARIANTS[variant])
     if reference:
         ns = ref_driver.load_modeling()
         n = len(cfg["out_features"])
@@ -198,12 +199,16 @@ def main_train():
     """One training step (mtmadise.py:180-656, shipped Depth flags, 64 x 64) through oracle/train_path.OracleMTMADISE with
     the REFERENCE's DAFormerHead and CmdiseCriterion; losses, gradient checksums of every trainable tensor, full
     gradients of the small non-UNet tensors, pseudo labels and BatchNorm running statistics."""
+    from golden_util import TRAIN_VARIANTS
     torch.set_num_threads(os.cpu_count())
-    t0 = time.time()
-    out = run_train_step(build_train_oracle(reference=True))
-    np.savez_compressed(os.path.join(HERE, "train_depth.npz"), **out)
-    print(f"train_depth: {time.time() - t0:.1f}s", {k: float(v) for k, v in out.items() if k.startswith("loss_")},
-          len(out["grad_rows"]), "gradient tensors")
+    for variant in TRAIN_VARIANTS:
+        if sys.argv[1:] and variant not in sys.argv[1:]:
+            continue
+        t0 = time.time()
+        out = run_train_step(build_train_oracle(reference=True, variant=variant))
+        np.savez_compressed(os.path.join(HERE, variant + ".npz"), **out)
+        print(f"{variant}: {time.time() - t0:.1f}s", {k: float(v) for k, v in out.items() if k.startswith("loss_")},
+              len(out["grad_rows"]), "gradient tensors")
 
 
 def main_labels():
@@ -229,7 +234,7 @@ def main_labels():
 
 
 if __name__ == "__main__":
-    if "train_depth" in sys.argv[1:] or not sys.argv[1:]:
+    if not sys.argv[1:] or any(a.startswith("train_") for a in sys.argv[1:]):
         main_train()
     if "labels" in sys.argv[1:] or not sys.argv[1:]:
         main_labels()

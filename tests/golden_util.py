@@ -62,6 +62,9 @@ EVAL_CASES = {
     "eval_s345": dict(cfg="S345", H=480, W=640),
     # the shipped RGB->Depth configuration: VAE decoder -> s0 projection -> head at 512x512
     "eval_depth": dict(cfg="DEPTH", H=512, W=512),
+    # the shipped RGB->Infrared configuration (K = 9, FMB test images are resized to 512 x 512 by the mapper,
+    # config_files/common/data/cityscapes_rgb_to_fmb_9_infrared_semseg.py:43); RGB->Event is the Depth graph (K = 11)
+    "eval_infrared": dict(cfg="INFRARED", H=512, W=512),
 }
 
 
@@ -99,6 +102,14 @@ def label_inputs(B, K, H, W, **_):
 # ---- one training step of the shipped RGB->Depth configuration at 64 x 64 (tests/golden/train_depth.npz) --------------
 TRAIN_CASE = dict(B=2, size=64, K=11, py_seed=20240, np_seed=20241, full_grad_max_numel=70000,
                   pseudo_threshold=0.25)     # low threshold: random-weight teachers are never 96.8 % confident
+# model arguments of the shipped task configs (config_files/SemSeg/MTMADISE/*.py) that differ between the fixtures
+TRAIN_VARIANTS = {
+    "train_depth": dict(vae_decoder_loss='st', vae_decoder_loss_weight=[1.0, 1.0], denoise_timestep_range=[60, 61],
+                        rev_noise_end_iter=5000),
+    # mtmadise_cityscapes_rgb_to_event_11.py:43-58: source-only decoder loss with weight 20, teacher noise step 50
+    "train_event": dict(vae_decoder_loss='s', vae_decoder_loss_weight=[20.0], denoise_timestep_range=[50, 51],
+                        rev_noise_end_iter=8000),
+}
 
 
 def train_inputs(B, size, K, **_):

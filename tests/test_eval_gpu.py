@@ -121,7 +121,7 @@ def _build_product(cfg_name, dtype):
     from madm_amd.head import DAFormerHead
     from madm_amd.meta_arch import MadmInference
     from oracle import madm_path
-    cfg = madm_path.DEPTH_CFG if cfg_name == "DEPTH" else madm_path.S345_CFG
+    cfg = madm_path.cfg_by_name(cfg_name)
     ldm = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=(),
                   input_range='-1+1', unet_block_indices_type='after', finetune_unet='no', compute_dtype=dtype,
                   weights='synthetic', seed=0, vae_decoder_loss=cfg["vae_decoder_loss"])
@@ -139,7 +139,7 @@ def _build_product(cfg_name, dtype):
     return model
 
 
-@pytest.mark.parametrize("name", ["eval_s345", "eval_depth"])
+@pytest.mark.parametrize("name", ["eval_s345", "eval_depth", "eval_infrared"])
 @pytest.mark.parametrize("dtype", DTYPES + [torch.float16], ids=["f32", "bf16", "f16"])
 def test_eval_forward_golden(cuda, name, dtype):
     """MTMADISE eval forward (mtmadise.py:657-691) end to end vs the vectors of the reference's own classes."""

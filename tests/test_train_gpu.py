@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from golden_util import (TRAIN_CASE, train_inputs, train_palette, train_dropout_scales, grad_probe, init_eval_params,
+from golden_util import (TRAIN_CASE, TRAIN_VARIANTS, train_inputs, train_palette, train_dropout_scales, grad_probe, init_eval_params,
                          load_golden)
 from util import rel_err, to_tokens, from_tokens
 
@@ -168,7 +168,7 @@ def test_masked_l1_and_tanh_gate_backward(cuda):
 
 
 # ----------------------------------------------------------------------------- one full training step
-def build_product_train(dtype, **kw):
+def build_product_train(dtype, variant="train_depth", **kw):
     from madm_amd.ldm_rocm import LdmRocm
     from madm_amd.backbone import BasePromptTimeGenerator, AttentionFeatureExtractorBackbone
     from madm_amd.head import DAFormerHead
@@ -195,25 +195,29 @@ def build_product_train(dtype, **kw):
                 vae_decoder_loss_type='L1', vae_decoder_loss_weight=[1.0, 1.0], reg_uncertain=True, rev_noise_sup=True,
                 rev_noise_end_iter=5000, rev_noise_gradually=True, denoise_timestep_range=[60, 61], max_iter=10000,
                 pseudo_threshold=TRAIN_CASE["pseudo_threshold"], color_aug_flag=False)
+    args.update(TRAIN_VARIANTS[variant])
     args.update(kw)
     model = MTMADISE(backbone.cuda(), head.cuda(), CmdiseCriterion(num_classes=cfg["num_classes"]), **args)
     return model.train()
 
 
-@pytest.mark.parametrize("dtype", DT, ids=IDS)
-def test_train_step_matches_fixture(cuda, dtype):
+@pytest.mark.parametrize("variant,dtype", [("train_depth", torch.float32), ("train_depth", torch.bfloat16),
+                                           ("train_depth", torch.float16), ("train_event", torch.float32)],
+                         ids=["depth-f32", "depth-bf16", "depth-f16", "event-f32"])
+def test_train_step_matches_fixture(cuda, variant, dtype):
     """model(list[dict]) -> loss dict; sum(losses).backward(): every loss scalar, the pseudo labels / mixed labels (bit
     exact in f32 mode), the BatchNorm running statistics and the gradient of EVERY trainable tensor (l2 norm and a seeded
     probe checksum; the small non-UNet tensors in full) vs tests/golden/train_depth.npz."""
-    gold = load_golden("train_depth")
-    model = build_product_train(dtype)
+    gold = load_golden(variant)
+    model = build_product_train(dtype, variant)
     sc = train_dropout_scales(TRAIN_CASE["B"])
     model.sem_seg_head.dropout_scale_override = [sc[0], sc[1]]
     model.ema_sem_seg_head.dropout_scale_override = [sc[2]]
     random.seed(TRAIN_CASE["py_seed"])
     np.random.seed(TRAIN_CASE["np_seed"])
     losses = model(train_inputs(**TRAIN_CASE))
-    assert set(losses) == {"source_loss", "target_loss", "vae_decoder_source_loss", "vae_decoder_target_loss"}
+    assert set(losses) == {"source_loss", "target_loss", "vae_decoder_source_loss"} | \
+        ({"vae_decoder_target_loss"} if variant == "train_depth" else set())
     # 16-bit modes: a GradScaler-style loss scale, as the reference's fp16 AMP run has (engine/train_loop.py:203-217) --
     # d loss / d logits is ~1 / (B H W) and would sink into fp16's subnormals deep in the network
     gscale = 1.0 if dtype == torch.float32 else 4096.0
@@ -246,7 +250,7 @@ def test_train_step_matches_fixture(cuda, dtype):
         assert (e < 1e-3) if f32 else (l2 < (2e-2 if dtype == torch.float16 else 1e-1)), (name, e, l2)
     # gradients
     import numpy as _np
-    z = _np.load(__import__("os").path.join(__import__("golden_util").GOLDEN_DIR, "train_depth.npz"))
+    z = _np.load(__import__("os").path.join(__import__("golden_util").GOLDEN_DIR, variant + ".npz"))
     names = str(z["grad_names"]).split("\n")
     rows = z["grad_rows"]
     params = dict(model.named_parameters())
