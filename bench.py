@@ -158,6 +158,8 @@ def run_train(args, rank, world, device, dist, mdist):
                           "global_batch": args.batch * world,
                           "parallelism": f"dp{world}: gradient all-reduce(mean) over the flat fp32 buffer" if world > 1 else "dp1",
                           "launch": "eager"},
+               "allreduce_exposed_ms": trainer.last_allreduce_exposed_ms,
+               "allreduce_started_during_backward_frac": trainer.last_overlap_frac,
                "last_losses": losses, "grad_norm": norm, "stepped": stepped, "loss_scale": trainer.scale,
                "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
         print(json.dumps(out), flush=True)

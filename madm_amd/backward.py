@@ -450,14 +450,16 @@ def unet_forward_recorded(unet, sample, timesteps, ctx, Lk, unet_block_indices, 
     return out, tapped, st
 
 
-def unet_backward_from_state(st, dtaps, dsample=None, base_grads=True):
+def unet_backward_from_state(st, dtaps, dsample=None, base_grads=True, grad_cb=None):
     """Reverse walk over the tape of :func:`unet_forward_recorded` for the gradients ``dtaps`` of the tapped features
     ([M_i, C_i] tensors, same order) and, optionally, ``dsample`` of the final sample ([M, n_pad]); every block's
     backward recomputes its interior.
 
     Returns {"sample": d latents [M, Cpad], "ctx": d prompt tokens [B*Lk, 768], "cond_emb": f32 [B, 1280] or None,
     "grads": {parameter name: f32 gradient}} -- with ``base_grads=False`` (the reference's LoRA mode) only LoRA A / B,
-    the norms' affine parameters and the time-row projections come back."""
+    the norms' affine parameters and the time-row projections come back.  ``grad_cb(name, tensor)``: called for every
+    parameter gradient AS SOON AS its block's backward has run (up blocks first, conv_in last, then the batched K/V and
+    time-embedding tails) instead of collecting them -- the hook the overlapped gradient all-reduce hangs on."""
     unet, sample, ctx, Lk, cond_emb, dtype, B, names = st.unet, st.sample, st.ctx, st.Lk, st.cond_emb, st.dtype, st.B, st.names
     tape, rows, kvs, emb, e1, a1, t_emb, h, tapped = st.tape, st.rows, st.kvs, st.emb, st.e1, st.a1, st.t_emb, st.h, st.tapped
     rec = tape.records
@@ -466,7 +468,14 @@ def unet_backward_from_state(st, dtaps, dsample=None, base_grads=True):
     for tk, g in zip(tapped, dtaps):
         tape.add(tk.t, g)
 
-    grads = {}
+    class _Grads(dict):
+        def __setitem__(self, k_, v):
+            if grad_cb is not None:
+                grad_cb(k_, v)
+            else:
+                dict.__setitem__(self, k_, v)
+
+    grads = _Grads()
     dctx = None
     drow = {}
     dkv_of = {}

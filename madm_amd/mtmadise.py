@@ -296,7 +296,8 @@ class MTMADISE(MadmInference):
     # ------------------------------------------------------------------ backward of one recorded student pass
     def _backward_pass(self, rec, dlogits, dsample, add):
         """dlogits: tokens [M, k_tile] (compute dtype) or None; dsample: NCHW f32 gradient of 'before_vae.decoder' or None;
-        ``add(param, grad)`` accumulates a parameter gradient."""
+        ``add(param, grad)`` accumulates a parameter gradient (called in the order the backward produces them: head,
+        projections, UNet up -> mid -> down -> conv_in, batched K/V and time-embedding tails, prompt / time gates)."""
         bb = self.backbone
         gen = bb.feature_extractor
         ldm = gen.ldm_extractor
@@ -325,11 +326,13 @@ class MTMADISE(MadmInference):
             ds = ops.nchw_to_nhwc(dsample.float().contiguous(), dtype, max(unet.conv_out.n_pad, 16 // dsample.new_empty(0, dtype=dtype).element_size()))
         up = dict(unet.named_parameters())
         base = any(p.requires_grad and ".lora_" not in n for n, p in up.items())
-        res = bw.unet_backward_from_state(state, dtaps, dsample=ds, base_grads=base)
-        for k_, v in res["grads"].items():
+
+        def unet_grad(k_, v):
             p = up.get(k_)
             if p is not None and p.requires_grad:
                 add(p, v)
+
+        res = bw.unet_backward_from_state(state, dtaps, dsample=ds, base_grads=base, grad_cb=unet_grad)
         # prompt / time conditioning
         project = rec["project"]
         if any(p.requires_grad for p in project.parameters()):
@@ -359,22 +362,39 @@ class _TrainStepFn(torch.autograd.Function):
         crit = model.criterion
         g = {n: (go if go is not None else None) for n, go in zip(names, gouts)}
         acc = {}
-
-        def add(p, v):
-            v = v.reshape(p.shape)
-            cur = acc.get(id(p))
-            acc[id(p)] = v if cur is None else cur + v
-
+        touched = set()
+        sink = getattr(model, "grad_sink", None)     # train.MadmTrainer: gradients go straight into its flat buffer and
+        passes = []                                  # finished spans are all-reduced while the backward still runs
         dtype = st["rec_s"]["keep"]["dtype"]
         for rec, ce_name, dec_name in ((st["rec_s"], 'source_loss', 'vae_decoder_source_loss'),
                                        (st["rec_t"], 'target_loss', 'vae_decoder_target_loss')):
+            if (g.get(ce_name) is not None) or (dec_name in ctxs and g.get(dec_name) is not None):
+                passes.append((rec, ce_name, dec_name))
+        for i, (rec, ce_name, dec_name) in enumerate(passes):
+            last = i == len(passes) - 1
+
+            def add(p, v, last=last):
+                v = v.reshape(p.shape)
+                touched.add(id(p))
+                cur = acc.pop(id(p), None) if (last and sink is not None) else acc.get(id(p))
+                tot = v if cur is None else cur + v
+                if last and sink is not None:
+                    sink.final(p, tot)               # a parameter shared by several producers (prompt gates) arrives twice:
+                else:                                # the sink accumulates
+                    acc[id(p)] = tot
+
             dlogits = crit.ce_backward(ctxs[ce_name], g[ce_name], dtype) if g.get(ce_name) is not None else None
             dsample = None
             if dec_name in ctxs and g.get(dec_name) is not None:
                 dsample = crit.decoder_loss_backward(ctxs[dec_name], g[dec_name])
-            if dlogits is None and dsample is None:
-                continue
             model._backward_pass(rec, dlogits, dsample, add)
         st["rec_s"] = st["rec_t"] = None       # free the tapes
-        model.last_grad_param_ids = set(acc.keys())    # torch.optim.AdamW skips parameters whose grad is None
+        model.last_grad_param_ids = touched    # torch.optim.AdamW skips parameters whose grad is None
+        if sink is not None:
+            for p in params:                   # gradients only the first pass produced
+                v = acc.pop(id(p), None)
+                if v is not None:
+                    sink.final(p, v)
+            sink.backward_done()
+            return (None, None) + (None,) * ctx.n_losses + (None,) * len(params)
         return (None, None) + (None,) * ctx.n_losses + tuple(acc.get(id(p)) for p in params)

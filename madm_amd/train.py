@@ -28,10 +28,29 @@ class MadmTrainer:
         table = optim.default_optimizer_params(model, lr, weight_decay, weight_decay_norm=0.0, weight_decay_bias=0.0,
                                                unet_lr=unet_lr)
         assert table, "nothing to train"
+        # flat-buffer order = the order in which the explicit backward FINISHES gradients, reversed: parameters whose
+        # gradient only exists at the very end of the backward (prompt / time gates, the time-embedding MLP and the
+        # stacked time_emb_proj / batched cross-attention K/V projections, backward.unet_backward_from_state's tails) go
+        # first, everything else follows in registration order (conv_in ... up blocks, projections, head) -- the backward
+        # walks that part back to front, so finished gradients always form a growing TAIL of the buffer
+        names = {id(p): n for n, p in model.named_parameters()}
+
+        def late(p):
+            n = names[id(p)]
+            return ("clip_project" in n or ".time_embedding." in n or ".time_emb_proj." in n or
+                    (".attn2.to_k." in n or ".attn2.to_v." in n))
+
+        table = [t for t in table if late(t[0])] + [t for t in table if not late(t[0])]
         self.opt = optim.TableAdamW(table, betas=betas, eps=eps)
         self.grad_clip = grad_clip
         self.dist = dist
         self.reducer = GradBucketReducer(self.opt.flat.grad, dist)
+        self._index = {id(p): i for i, p in enumerate(self.opt.flat.params)}
+        self._final = [False] * len(self.opt.flat.params)
+        self._ptr = len(self._final) - 1
+        self.overlap = dist is not None and dist.get_world_size() > 1
+        model.grad_sink = self
+        self.reduced_during_backward = 0       # elements whose all-reduce started before the backward returned
         if dist is not None and dist.get_world_size() > 1:
             dist.broadcast(self.opt.flat.flat, src=0)
             torch.autograd.graph.increment_version(self.opt.flat.params)
@@ -43,16 +62,48 @@ class MadmTrainer:
         self._growth_tracker = 0
         self.lr_multiplier = lr_multiplier          # callable(iter) -> factor (WarmupParamScheduler in the shipped config)
         self.iter = 0
+        self.last_allreduce_exposed_ms = None
+        self.last_overlap_frac = None
+
+    # ---- gradient sink of MTMADISE's autograd node: gradients land in the flat buffer, finished tails are reduced ----
+    def final(self, p, g):
+        i = self._index[id(p)]
+        assert not self._final[i], "a gradient arrived after its span was handed to the all-reduce"
+        p.grad.add_(g.reshape(p.shape).to(p.grad.dtype))
+        self._final[i] = True
+        if not self.overlap:
+            return
+        ptr = self._ptr
+        while ptr >= 0 and self._final[ptr]:
+            ptr -= 1
+        if ptr != self._ptr:
+            lo = self.opt.flat.offsets[ptr + 1]
+            if self.reducer.done_lo - lo >= self.reducer.bucket or ptr < 0:   # whole buckets only: few, large messages
+                self.reduced_during_backward += self.reducer.done_lo - lo
+                self.reducer.reduce_tail(lo)
+            self._ptr = ptr
+
+    def backward_done(self):
+        pass
 
     def run_step(self, data):
         """Returns (loss dict of python floats, total gradient norm, stepped)."""
         model = self.model
         assert model.training, "[MadmTrainer] model was changed to eval mode!"
         self.opt.zero_grad()
+        self._final = [False] * len(self._final)
+        self._ptr = len(self._final) - 1
+        self.reduced_during_backward = 0
         loss_dict = model(data)
         losses = sum(loss_dict.values())
         (losses * self.scale).backward()
+        ev = None
+        if self.overlap and torch.cuda.is_available() and self.opt.flat.grad.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         self.reducer.finish()
+        if ev is not None:
+            ev[1].record()
         if self.lr_multiplier is not None:
             self.opt.lr_factor = float(self.lr_multiplier(self.iter))
         touched = getattr(model, "last_grad_param_ids", None)
@@ -67,6 +118,10 @@ class MadmTrainer:
                     self.scale *= self.growth_factor
                     self._growth_tracker = 0
         self.iter += 1
+        if ev is not None:      # all-reduce time the compute stream had to WAIT for after the backward (the exposed part)
+            ev[1].synchronize()
+            self.last_allreduce_exposed_ms = ev[0].elapsed_time(ev[1])
+            self.last_overlap_frac = self.reduced_during_backward / max(1, self.opt.flat.numel)
         return {k: float(v.detach()) for k, v in loss_dict.items()}, norm, stepped
 
 

@@ -107,3 +107,93 @@ def test_gradient_reducer_is_a_no_op_for_one_rank():
     red.reduce_tail(4)
     red.finish()
     assert torch.equal(g, torch.arange(10, dtype=torch.float32))
+
+
+class _TinyTrainModel(torch.nn.Module):
+    """Stand-in with MTMADISE's parameter-name families (what MadmTrainer's flat-buffer ordering keys on)."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        mk = lambda *s: torch.nn.Parameter(torch.randn(*s, generator=g))
+        self.backbone = torch.nn.Module()
+        self.backbone.clip_project_rgb = torch.nn.ParameterDict({"prompt_embed": mk(7, 5)})
+        unet = torch.nn.Module()
+        unet.conv_in = torch.nn.ParameterDict({"weight": mk(2000)})
+        unet.time_embedding = torch.nn.ParameterDict({"weight": mk(300)})
+        unet.res = torch.nn.Module()
+        unet.res.time_emb_proj = torch.nn.ParameterDict({"weight": mk(500)})
+        unet.res.conv1 = torch.nn.ParameterDict({"weight": mk(3000)})
+        unet.up = torch.nn.ParameterDict({"weight": mk(2500)})
+        self.backbone.unet = unet
+        self.sem_seg_head = torch.nn.ParameterDict({"weight": mk(1500), "bias": mk(11)})
+
+
+def _trainer_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from madm_amd import dist as mdist
+    from madm_amd.train import MadmTrainer
+    d = mdist.init(backend="gloo")
+    model = _TinyTrainModel()
+    if rank == 1:                                   # ranks start from DIFFERENT parameters: rank 0's are broadcast
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    tr = MadmTrainer(model, lr=1e-3, weight_decay=0.05, dist=d)
+    tr.reducer.bucket = 2048                        # small buckets so that several collectives start during the "backward"
+    params0 = tr.opt.flat.flat.clone()
+    order = [n for n, _ in model.named_parameters()]
+    flat_names = [dict((id(p), n) for n, p in model.named_parameters())[id(p)] for p in tr.opt.flat.params]
+    # the explicit backward finishes gradients back to front: head, up, res.conv1, conv_in, then the late tails
+    tr.opt.zero_grad()
+    seq = ["sem_seg_head.weight", "sem_seg_head.bias", "backbone.unet.up.weight", "backbone.unet.res.conv1.weight",
+           "backbone.unet.conv_in.weight", "backbone.unet.res.time_emb_proj.weight", "backbone.unet.time_embedding.weight",
+           "backbone.clip_project_rgb.prompt_embed"]
+    named = dict(model.named_parameters())
+    for n in seq:
+        p = named[n]
+        tr.final(p, torch.full(p.shape, float(rank + 1)) * (1 + len(n)))
+    during = tr.reduced_during_backward
+    tr.reducer.finish()
+    # numpy arrays travel by value (torch tensors go through shared-memory handles that die with the worker)
+    q.put((rank, params0.numpy(), tr.opt.flat.grad.numpy().copy(), flat_names, during, [tr.opt.flat.offsets[i] for i in range(len(seq))]))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_trainer_broadcast_flat_order_and_overlapped_reduce_two_rank_gloo():
+    """MadmTrainer's DDP contract on CPU / gloo (no kernels involved): rank 0's parameters are broadcast at construction
+    (main.py:289-294), the flat buffer puts the late-finishing gradients first, finished tails are all-reduced in whole
+    buckets WHILE the remaining gradients still arrive, and every rank ends with the mean gradient."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, g0, names0, during0, _), (_, p1, g1, names1, during1, _) = res
+    p0, g0, p1, g1 = (torch.from_numpy(a) for a in (p0, g0, p1, g1))
+    assert torch.equal(p0, p1)                                        # broadcast: identical start
+    assert names0 == names1 and names0[:3] == ["backbone.clip_project_rgb.prompt_embed", "backbone.unet.time_embedding.weight",
+                                                "backbone.unet.res.time_emb_proj.weight"]
+    assert names0[3:] == ["backbone.unet.conv_in.weight", "backbone.unet.res.conv1.weight", "backbone.unet.up.weight",
+                          "sem_seg_head.bias", "sem_seg_head.weight"]      # (ParameterDict sorts its keys)
+    assert torch.equal(g0, g1)                                        # every rank holds the same (mean) gradient
+    assert during0 == during1 and during0 >= 2 * 2048                 # buckets were handed over before the backward ended
+    m = _TinyTrainModel()
+    tot = 0
+    named = dict(m.named_parameters())
+    # mean over the two ranks of (rank + 1) * (1 + len(name)) = 1.5 * (1 + len(name)), padding stays zero
+    from madm_amd import optim
+    for n in names0:
+        numel = named[n].numel()
+        assert torch.all(g0[tot:tot + numel] == 1.5 * (1 + len(n))), n
+        pad = (numel + 1023) // 1024 * 1024
+        assert torch.all(g0[tot + numel:tot + pad] == 0)
+        tot += pad
