@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
 
 int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
 inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8) || t == 11; }
-inline bool is_halo_tile(int t) { return t == 4 || t == 5 || t == 9 || t == 10; }
+inline bool is_halo_tile(int t) { return t == 4 || t == 5 || t == 9 || t == 10 || t == 12; }
 
 // Launch configurations measured on MI355X by tools/tune_insitu.py for the layer shapes of the SD-v1-4
 // feature extractor at bs=2, 512x512 (any other shape falls back to the heuristics below).
@@ -600,12 +600,13 @@ bool halo_eligible(const madm_conv2d_args* a) {
 // tile codes: 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 BN=128, 5 = halo BN=64,
 // 6 = igemm 64x64 with an 8-deep register prefetch (latency-bound small-M GEMMs streaming cold weights),
 // 7 / 8 = LDS-DMA igemm 64x64 (4-slot ring) / 128x64 (3-slot ring), 9 / 10 = halo BN=128 / BN=64 with LDS-DMA weights,
-// 11 = LDS-DMA igemm 64x64 with a 3-slot ring (48 KB: three blocks per CU, for grids of 513 .. 768 tiles)
-int pick_tile(const madm_conv2d_args* a) {
+// 11 = LDS-DMA igemm 64x64 with a 3-slot ring (48 KB: three blocks per CU, for grids of 513 .. 768 tiles),
+// 12 = halo conv3x3 on 16 x 16-pixel patches, BN = 128, halo and weights by LDS-DMA (conv3x3_h16.hip; maps >= 16 x 16)
+int pick_tile_raw(const madm_conv2d_args* a) {
     const int M = a->B * a->OH * a->OW, K = a->KH * a->KW * (a->C1 + a->C2);
     const bool halo_ok = halo_eligible(a);
     const int halo_default = (a->N % 128 == 0 || a->N >= 512) ? 4 : 5;
-    if (a->gn_sums1) {   // fused GroupNorm exists only in the halo kernel
+    if (a->gn_sums1) {   // fused GroupNorm exists only in the halo kernels
         if (is_halo_tile(g_tile_override)) return g_tile_override;
         if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH, variant_of(a)))
             if (is_halo_tile(t->tile)) return t->tile;
@@ -618,8 +619,25 @@ int pick_tile(const madm_conv2d_args* a) {
     return heuristic_tile(M, a->N);
 }
 
+// the 16 x 16-patch kernel pays where it fills the chip: at least ~0.75 rounds of its 256-pixel x 128-channel blocks
+// (measured against tile 9 on MI355X, bf16 / f16: +12 .. 23 % on the 512^2 .. 128^2 maps of the VAE, 0.6 x on an 8192-pixel map)
+bool h16_pays(const madm_conv2d_args* a) {
+    static const int off = [] { const char* e = getenv("MADM_NO_H16"); return e ? atoi(e) : 0; }();
+    if (off || a->OH < 16 || a->OW < 16 || a->N < 128) return false;
+    const long long blocks = (long long)a->B * ((a->OH + 15) / 16) * ((a->OW + 15) / 16) * ((a->N + 127) / 128);
+    return blocks >= 384;
+}
+
+int pick_tile(const madm_conv2d_args* a) {
+    const int t = pick_tile_raw(a);
+    if (t == 12 && (a->OH < 16 || a->OW < 16)) return 9;   // the 16 x 16-patch kernel needs a map of at least one patch
+    if ((t == 4 || t == 9) && g_tile_override == 0 && h16_pays(a)) return 12;
+    return t;
+}
+
 void tile_dims(int t, int& bm, int& bn) {
-    if (t == 1 || t == 4 || t == 9) { bm = 128; bn = 128; }
+    if (t == 12) { bm = 256; bn = 128; }
+    else if (t == 1 || t == 4 || t == 9) { bm = 128; bn = 128; }
     else if (t == 2 || t == 5 || t == 8 || t == 10) { bm = 128; bn = 64; }
     else { bm = 64; bn = 64; }
 }
@@ -713,7 +731,8 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
     tile_dims(t, bm, bn);
     int rc;
     if (is_halo_tile(t)) {
-        rc = (t >= 9) ? launch_conv3x3_halo_dma<T>(p, bn, s) : launch_conv3x3_halo<T>(p, bn, s);
+        rc = (t == 12) ? launch_conv3x3_h16<T>(p, bn, s)
+                       : ((t >= 9) ? launch_conv3x3_halo_dma<T>(p, bn, s) : launch_conv3x3_halo<T>(p, bn, s));
     } else {
         p.tilesN = (p.N + bn - 1) / bn;
         const int tilesM = (p.M + bm - 1) / bm;

@@ -214,3 +214,5 @@ __device__ __forceinline__ void stats_add_elementwise(const IgemmP& p, int m, in
 template <typename T> int launch_conv3x3_halo(const IgemmP& p, int bn, hipStream_t s);
 // conv3x3_dma.hip: the same with the weight tiles moved by LDS-DMA (three-slot ring, single halo buffer)
 template <typename T> int launch_conv3x3_halo_dma(const IgemmP& p, int bn, hipStream_t s);
+// conv3x3_h16.hip: 16 x 16-pixel patches, 128 x 64 wave tiles, halo and weights by LDS-DMA (maps of at least 16 x 16)
+template <typename T> int launch_conv3x3_h16(const IgemmP& p, int bn, hipStream_t s);

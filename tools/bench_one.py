@@ -27,10 +27,11 @@ def main():
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--check", type=int, default=0, help="compare the output (and fused statistics) with this tile code")
     args = ap.parse_args()
     from madm_amd import ops
     from madm_amd._lib import lib
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     H, W = args.hw
     B, Cin, Cout, k = args.B, args.cin, args.cout, args.k
     x = torch.randn((B * H * W, Cin), device="cuda").to(dtype)
@@ -52,6 +53,20 @@ def main():
         return ops.conv2d(x, w, B, H, W, N=Cout, KH=k, KW=k, pad_t=k // 2, pad_l=k // 2, bias=bias, stats=st, gn=gn, residual=res,
                           splitk=args.splitk)
 
+    if args.check:
+        if st is not None:
+            st.zero_()
+        out = run().float().clone()
+        st_a = None if st is None else st.clone()
+        lib.madm_debug_set_conv_tile(args.check)
+        it[0] -= 1
+        if st is not None:
+            st.zero_()
+        ref = run().float().clone()
+        lib.madm_debug_set_conv_tile(args.tile)
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        serr = 0.0 if st is None else ((st_a - st).abs().max() / st.abs().max()).item()
+        print(f"check vs tile {args.check}: max rel err {err:.3e}, stats rel err {serr:.3e}", "OK" if err < 2e-2 and serr < 1e-3 else "MISMATCH")
     for _ in range(3):
         run()
     torch.cuda.synchronize()
