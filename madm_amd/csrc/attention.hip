@@ -1,6 +1,8 @@
 // Flash-style attention forward for gfx950 (madm_attention_fwd).
 //
-// Workgroup = NW waves, wave w owns 16 query rows; KV is walked in tiles of NS*16 keys staged in
+// Workgroup = NW waves, wave w owns NQ groups of 16 query rows (NQ = 2 on the long self-attention maps: every K / V
+// fragment read from LDS then feeds two MFMAs, and the per-tile costs -- next tile's global loads, the LDS hand-over,
+// the barrier -- are paid once per 56 MFMAs instead of 28); KV is walked in tiles of NS*16 keys staged in
 // LDS.  Everything is kept "query on lane & 15":
 //   S^T = K Q^T   (MFMA a = K rows, b = Q rows)  -> lane holds one query, keys 4g..4g+3 per sub-tile
 //   row max / sum = in-lane over registers + two xor-shuffles (16, 32)
@@ -29,10 +31,10 @@ struct AttnP {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <typename T, int NKB, int ND, int NW, int NS>
+template <typename T, int NKB, int ND, int NW, int NS, int NQ = 1>
 struct AttnCfg {
     static constexpr int ES = sizeof(T);
-    static constexpr int BQ = NW * 16, BKV = NS * 16;
+    static constexpr int BQ = NW * 16 * NQ, BKV = NS * 16;
     static constexpr int QK_CH = NKB * 4;            // 16-byte chunks per Q/K row (padded)
     static constexpr int QK_ROWB = NKB * 64 + 16;    // +16 B pad: odd number of 16-B slots
     static constexpr int V_CH = ND * ES;             // chunks per V row: ND*16 elements
@@ -45,21 +47,24 @@ struct AttnCfg {
     static constexpr int VI0 = (BKV * V_CH + NT - 1) / NT;    // V chunks staged per thread (upper bound)
     static constexpr bool PIPE = (BQ * QK_ROWB + 2 * KV_TILE_B) <= 112 * 1024 && (KI0 + VI0) <= 12 && NKB <= 6;
     static constexpr int NBUF = PIPE ? 2 : 1;
-    static constexpr size_t LDS_BYTES = (size_t)BQ * QK_ROWB + (size_t)NBUF * KV_TILE_B;
+    // PIPE: the Q tile is only staged to be read into registers before the KV loop starts; it shares the LDS of the SECOND
+    // KV buffer (first written at the end of tile 0) -- two blocks per CU stay resident with 128-query blocks
+    static constexpr bool Q_ALIAS = PIPE && BQ * QK_ROWB <= KV_TILE_B;
+    static constexpr size_t LDS_BYTES = (Q_ALIAS ? 0 : (size_t)BQ * QK_ROWB) + (size_t)NBUF * KV_TILE_B;
     static constexpr int KI = PIPE ? KI0 : 1, VI = PIPE ? VI0 : 1;
 };
 
 typedef unsigned int u32x4a __attribute__((ext_vector_type(4)));
 
-template <typename T, int NKB, int ND, int NW, int NS>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
-    using C = AttnCfg<T, NKB, ND, NW, NS>;
+template <typename T, int NKB, int ND, int NW, int NS, int NQ = 1>
+__global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const AttnP p) {
+    using C = AttnCfg<T, NKB, ND, NW, NS, NQ>;
     constexpr int ES = C::ES;
     constexpr int NT = C::NT;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Qs = smem;
-    char* KV0 = Qs + C::BQ * C::QK_ROWB;
+    char* KV0 = smem + (C::Q_ALIAS ? 0 : C::BQ * C::QK_ROWB);
+    char* Qs = C::Q_ALIAS ? KV0 + C::KV_TILE_B : smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, fg = lane >> 4;
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
         vgo[i] = (unsigned)((size_t)r * p.ldv * ES + c * 16);
         vlo[i] = r * C::V_ROWB + c * 16;
     }
-    for (int nb = 0; nb < C::NBUF; ++nb) {   // zero the padding chunks once
+    for (int nb = 0; nb < (C::Q_ALIAS ? 1 : C::NBUF); ++nb) {   // zero the padding chunks once (aliased buffer 1: after Q is read)
         char* Kb = KV0 + nb * C::KV_TILE_B;
         char* Vb = Kb + C::BKV * C::QK_ROWB;
         for (int idx = tid; idx < C::BKV * C::QK_CH; idx += NT) {
@@ -159,10 +164,15 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
         }                                                                                                  \
     }
 
-    f32x4 o[ND];
+    f32x4 o[NQ][ND];
+    float m_run[NQ], l_run[NQ];
 #pragma unroll
-    for (int d = 0; d < ND; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int g = 0; g < NQ; ++g) {
+        m_run[g] = -INFINITY;
+        l_run[g] = 0.f;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) o[g][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const int ntiles = (p.Lk + C::BKV - 1) / C::BKV;
     if constexpr (C::PIPE) {
@@ -173,11 +183,26 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
     }
     __syncthreads();   // Q, padding zeros and tile 0 visible
 
-    uint4 qreg[C::PIPE ? NKB : 1];
+    uint4 qreg[NQ][C::PIPE ? NKB : 1];
     if constexpr (C::PIPE) {
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-            qreg[kb] = *reinterpret_cast<const uint4*>(Qs + (wave * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
+        for (int g = 0; g < NQ; ++g)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+                qreg[g][kb] = *reinterpret_cast<const uint4*>(Qs + ((wave * NQ + g) * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
+        if constexpr (C::Q_ALIAS) {   // the Q staging area becomes KV buffer 1: restore its zero padding chunks
+            __syncthreads();
+            char* Kb = KV0 + C::KV_TILE_B;
+            char* Vb = Kb + C::BKV * C::QK_ROWB;
+            for (int idx = tid; idx < C::BKV * C::QK_CH; idx += NT) {
+                const int r = idx / C::QK_CH, c = idx - r * C::QK_CH;
+                if (c >= dch) *reinterpret_cast<uint4*>(Kb + r * C::QK_ROWB + c * 16) = make_uint4(0, 0, 0, 0);
+            }
+            for (int idx = tid; idx < C::BKV * C::V_CH; idx += NT) {
+                const int r = idx / C::V_CH, c = idx - r * C::V_CH;
+                if (c >= dch) *reinterpret_cast<uint4*>(Vb + r * C::V_ROWB + c * 16) = make_uint4(0, 0, 0, 0);
+            }
+        }
     }
 
     for (int t = 0; t < ntiles; ++t) {
@@ -193,69 +218,78 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
         const char* Vs = Ks + C::BKV * C::QK_ROWB;
 
         // ---- S^T = K Q^T for this wave's 16 queries ----
-        f32x4 s[NS];
+        f32x4 s[NQ][NS];
 #pragma unroll
-        for (int st = 0; st < NS; ++st) s[st] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < NQ; ++g)
+#pragma unroll
+            for (int st = 0; st < NS; ++st) s[g][st] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            uint4 qf;
-            if constexpr (C::PIPE) qf = qreg[kb];
-            else qf = *reinterpret_cast<const uint4*>(Qs + (wave * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
+            uint4 qf[NQ];
+#pragma unroll
+            for (int g = 0; g < NQ; ++g) {
+                if constexpr (C::PIPE) qf[g] = qreg[g][kb];
+                else qf[g] = *reinterpret_cast<const uint4*>(Qs + ((wave * NQ + g) * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
+            }
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
                 const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (st * 16 + fi) * C::QK_ROWB + (kb * 4 + fg) * 16);
-                mma16<T>(kf, qf, s[st]);
+#pragma unroll
+                for (int g = 0; g < NQ; ++g) mma16<T>(kf, qf[g], s[g][st]);
             }
         }
         A_STAMP(t, 1);
-        // ---- online softmax (base-2), one query per lane ----
-        float mx = -INFINITY;
-        if (k0 + C::BKV <= p.Lk) {   // full tile: no masking (wave-uniform)
+        // ---- online softmax (base-2), one query per lane and query group ----
 #pragma unroll
-            for (int st = 0; st < NS; ++st)
+        for (int g = 0; g < NQ; ++g) {
+            float mx = -INFINITY;
+            if (k0 + C::BKV <= p.Lk) {   // full tile: no masking (wave-uniform)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = s[st][r] * p.scale_log2;
-                    s[st][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-        } else {
+                for (int st = 0; st < NS; ++st)
 #pragma unroll
-            for (int st = 0; st < NS; ++st)
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = s[g][st][r] * p.scale_log2;
+                        s[g][st][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = k0 + st * 16 + fg * 4 + r;
-                    float v = s[st][r] * p.scale_log2;
-                    v = (key < p.Lk) ? v : -INFINITY;
-                    s[st][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-        }
-        // row maximum over the four lane groups of a query: v_permlane16/32_swap (VALU) instead of two ds_bpermute round
-        // trips -- this exchange sits on the critical path of every KV tile (the exponentials wait for it)
-        {
-            const unsigned xi = __builtin_bit_cast(unsigned, mx);
-            const auto r16 = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
-            mx = fmaxf(__builtin_bit_cast(float, r16[0]), __builtin_bit_cast(float, r16[1]));
-            const unsigned yi = __builtin_bit_cast(unsigned, mx);
-            const auto r32 = __builtin_amdgcn_permlane32_swap(yi, yi, false, false);
-            mx = fmaxf(__builtin_bit_cast(float, r32[0]), __builtin_bit_cast(float, r32[1]));
-        }
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
+                for (int st = 0; st < NS; ++st)
 #pragma unroll
-        for (int st = 0; st < NS; ++st)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[st][r] - m_new);
-                s[st][r] = e;
-                psum += e;
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = k0 + st * 16 + fg * 4 + r;
+                        float v = s[g][st][r] * p.scale_log2;
+                        v = (key < p.Lk) ? v : -INFINITY;
+                        s[g][st][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
             }
-        l_run = l_run * alpha + psum;  // per lane-group partial; groups are summed at the end
+            // row maximum over the four lane groups of a query: v_permlane16/32_swap (VALU) instead of two ds_bpermute round
+            // trips -- this exchange sits on the critical path of every KV tile (the exponentials wait for it)
+            {
+                const unsigned xi = __builtin_bit_cast(unsigned, mx);
+                const auto r16 = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);
+                mx = fmaxf(__builtin_bit_cast(float, r16[0]), __builtin_bit_cast(float, r16[1]));
+                const unsigned yi = __builtin_bit_cast(unsigned, mx);
+                const auto r32 = __builtin_amdgcn_permlane32_swap(yi, yi, false, false);
+                mx = fmaxf(__builtin_bit_cast(float, r32[0]), __builtin_bit_cast(float, r32[1]));
+            }
+            const float m_new = fmaxf(m_run[g], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
+            m_run[g] = m_new;
+            float psum = 0.f;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) o[d] *= alpha;
+            for (int st = 0; st < NS; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(s[g][st][r] - m_new);
+                    s[g][st][r] = e;
+                    psum += e;
+                }
+            l_run[g] = l_run[g] * alpha + psum;  // per lane-group partial; groups are summed at the end
+#pragma unroll
+            for (int d = 0; d < ND; ++d) o[g][d] *= alpha;
+        }
 
         A_STAMP(t, 2);
         // ---- O^T += V^T P^T ----
@@ -264,13 +298,17 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
             const int tq = fi >> 2, tp = fi & 3;
 #pragma unroll
             for (int u = 0; u < NS / 2; ++u) {
-                typename TT<T>::vec8 pf;
+                uint4 pfu[NQ];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pf[r] = (T)s[2 * u][r];
-                    pf[4 + r] = (T)s[2 * u + 1][r];
+                for (int g = 0; g < NQ; ++g) {
+                    typename TT<T>::vec8 pf;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pf[r] = (T)s[g][2 * u][r];
+                        pf[4 + r] = (T)s[g][2 * u + 1][r];
+                    }
+                    pfu[g] = __builtin_bit_cast(uint4, pf);
                 }
-                const uint4 pfu = __builtin_bit_cast(uint4, pf);
                 const char* va = Vs + ((2 * u) * 16 + fg * 4 + tq) * C::V_ROWB + tp * 8;
                 const char* vb = va + 16 * C::V_ROWB;
 #pragma unroll
@@ -281,14 +319,17 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                         (__attribute__((address_space(3))) s16x4*)(vb + d * 32));
                     uint2 a0 = __builtin_bit_cast(uint2, x0), a1 = __builtin_bit_cast(uint2, x1);
                     const uint4 vf = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                    mma16<T>(vf, pfu, o[d]);
+#pragma unroll
+                    for (int g = 0; g < NQ; ++g) mma16<T>(vf, pfu[g], o[g][d]);
                 }
             }
         } else {
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
-                const float4 pf4 = make_float4(s[st][0], s[st][1], s[st][2], s[st][3]);
-                const uint4 pfu = __builtin_bit_cast(uint4, pf4);
+                uint4 pfu[NQ];
+#pragma unroll
+                for (int g = 0; g < NQ; ++g)
+                    pfu[g] = __builtin_bit_cast(uint4, make_float4(s[g][st][0], s[g][st][1], s[g][st][2], s[g][st][3]));
                 const char* vr_ = Vs + (st * 16 + fg * 4) * C::V_ROWB + fi * 4;
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
@@ -297,7 +338,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
                     vf4.y = *reinterpret_cast<const float*>(vr_ + 1 * C::V_ROWB + d * 64);
                     vf4.z = *reinterpret_cast<const float*>(vr_ + 2 * C::V_ROWB + d * 64);
                     vf4.w = *reinterpret_cast<const float*>(vr_ + 3 * C::V_ROWB + d * 64);
-                    mma16<T>(__builtin_bit_cast(uint4, vf4), pfu, o[d]);
+#pragma unroll
+                    for (int g = 0; g < NQ; ++g) mma16<T>(__builtin_bit_cast(uint4, vf4), pfu[g], o[g][d]);
                 }
             }
         }
@@ -320,24 +362,28 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnP p) {
 #undef ATTN_STAGE_DIRECT
 
     // ---- finish: total row sum over the 4 lane groups, normalise, store 4 consecutive d ----
-    l_run += __shfl_xor(l_run, 16);
-    l_run += __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_run;
-    const int qi = q0 + wave * 16 + fi;
-    if (qi < p.Lq) {
-        T* orow = reinterpret_cast<T*>(p.o) + (size_t)(b * p.Lq + qi) * p.ldo + (size_t)h * p.D;
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const int dd = d * 16 + fg * 4;
-            if (dd < p.D) store4<T>(orow + dd, o[d] * inv);
+    for (int g = 0; g < NQ; ++g) {
+        float l = l_run[g];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int qi = q0 + (wave * NQ + g) * 16 + fi;
+        if (qi < p.Lq) {
+            T* orow = reinterpret_cast<T*>(p.o) + (size_t)(b * p.Lq + qi) * p.ldo + (size_t)h * p.D;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const int dd = d * 16 + fg * 4;
+                if (dd < p.D) store4<T>(orow + dd, o[g][d] * inv);
+            }
         }
     }
 }
 
-template <typename T, int NKB, int ND, int NW, int NS>
+template <typename T, int NKB, int ND, int NW, int NS, int NQ = 1>
 int launch_attn(const AttnP& p, hipStream_t s) {
-    using C = AttnCfg<T, NKB, ND, NW, NS>;
-    auto kern = attn_kernel<T, NKB, ND, NW, NS>;
+    using C = AttnCfg<T, NKB, ND, NW, NS, NQ>;
+    auto kern = attn_kernel<T, NKB, ND, NW, NS, NQ>;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
         if (C::LDS_BYTES > 64 * 1024) {
@@ -364,6 +410,9 @@ extern "C" int madm_debug_read_attn_stamps(unsigned long long* host, int n) {
 }
 #endif
 
+static const bool g_attn_nw8 = [] { const char* e = getenv("MADM_ATTN_NW8"); return e && atoi(e) != 0; }();
+static const bool g_attn_nq1 = [] { const char* e = getenv("MADM_ATTN_NQ1"); return e && atoi(e) != 0; }();   // A/B switch
+
 extern "C" int madm_attention_fwd(const madm_attention_args* a, void* stream) {
     MADM_REQUIRE(a && a->q && a->k && a->v && a->o, "attention: null pointer");
     MADM_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0 && a->D > 0, "attention: bad dims");
@@ -388,7 +437,8 @@ extern "C" int madm_attention_fwd(const madm_attention_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (a->dtype == MADM_BF16) {
         switch (a->D) {
-            case 40: return a->Lk >= 512 ? launch_attn<bf16_t, 2, 3, 4, 8>(p, s) : launch_attn<bf16_t, 2, 3, 4, 4>(p, s);
+            case 40: return a->Lk >= 512 ? (a->Lq >= 2048 && !g_attn_nq1 ? (g_attn_nw8 ? launch_attn<bf16_t, 2, 3, 8, 8, 2>(p, s) : launch_attn<bf16_t, 2, 3, 4, 8, 2>(p, s)) : launch_attn<bf16_t, 2, 3, 4, 8>(p, s))
+                                         : launch_attn<bf16_t, 2, 3, 4, 4>(p, s);
             case 64: return launch_attn<bf16_t, 2, 4, 4, 4>(p, s);
             case 80: return a->Lk >= 512 ? launch_attn<bf16_t, 3, 5, 4, 8>(p, s) : launch_attn<bf16_t, 3, 5, 4, 4>(p, s);
             case 160: return launch_attn<bf16_t, 5, 10, 4, 4>(p, s);
@@ -397,7 +447,8 @@ extern "C" int madm_attention_fwd(const madm_attention_args* a, void* stream) {
         }
     } else if (a->dtype == MADM_F16) {
         switch (a->D) {
-            case 40: return a->Lk >= 512 ? launch_attn<f16_t, 2, 3, 4, 8>(p, s) : launch_attn<f16_t, 2, 3, 4, 4>(p, s);
+            case 40: return a->Lk >= 512 ? (a->Lq >= 2048 && !g_attn_nq1 ? (g_attn_nw8 ? launch_attn<f16_t, 2, 3, 8, 8, 2>(p, s) : launch_attn<f16_t, 2, 3, 4, 8, 2>(p, s)) : launch_attn<f16_t, 2, 3, 4, 8>(p, s))
+                                         : launch_attn<f16_t, 2, 3, 4, 4>(p, s);
             case 64: return launch_attn<f16_t, 2, 4, 4, 4>(p, s);
             case 80: return a->Lk >= 512 ? launch_attn<f16_t, 3, 5, 4, 8>(p, s) : launch_attn<f16_t, 3, 5, 4, 4>(p, s);
             case 160: return launch_attn<f16_t, 5, 10, 4, 4>(p, s);

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--dtype", default="f16")
     ap.add_argument("--top", type=int, default=60)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--size", type=int, default=512)
@@ -20,7 +20,7 @@ def main():
     from madm_amd.ldm_rocm import LdmRocm
     from madm_amd import ops
     import bench
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     m = LdmRocm("", [], [5, 8, 11], [], input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
                 compute_dtype=dtype, weights='synthetic', seed=0)
     inputs = bench.make_inputs(args.batch, args.size, torch.device("cuda"))
