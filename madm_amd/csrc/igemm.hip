@@ -576,11 +576,12 @@ const Tuned* find_tuned(int dtype, int M, int N, int K, int KH, int variant) {
     return nullptr;
 }
 
-int heuristic_tile(int M, int N) {
+int heuristic_tile(int M, int N, int K) {
     auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    // prefer the largest tile that still gives the 256 CUs >= ~1.5 waves of work
-    if (M >= 128 && N >= 128 && tiles(128, 128) >= 384) return 1;
-    if (M >= 128 && tiles(128, 64) >= 256) return 2;
+    // shapes without a tuned entry (the segmentation head, the training step's gradients, other batch sizes): the
+    // register-staged 128 x 128 tile never wins a tuned entry and loses 25 .. 40 % on the head's M = 524 288 GEMMs
+    // (M524288: N256 K1024 851 us vs 612 (tile 8) / 630 (tile 2); N1024 K256 1447 vs 892 (tile 2); MI355X, f16)
+    if (M >= 128 && tiles(128, 64) >= 256) return K >= 1024 ? 8 : 2;
     return 3;
 }
 
@@ -616,7 +617,7 @@ int pick_tile_raw(const madm_conv2d_args* a) {
     if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH, variant_of(a)))
         if (is_igemm_tile(t->tile) || halo_ok) return t->tile;
     if (halo_ok && M >= 2048) return halo_default;
-    return heuristic_tile(M, a->N);
+    return heuristic_tile(M, a->N, K);
 }
 
 // the 16 x 16-patch kernel pays where it fills the chip: at least ~0.75 rounds of its 256-pixel x 128-channel blocks

@@ -52,6 +52,15 @@ def test_spatial_kernels(cuda, dtype):
         ref = F.relu(F.conv2d(xd, w, None, padding=dil, dilation=dil, groups=C) * s[None, :, None, None] + t[None, :, None, None])
         got = ops.dwconv3x3(to_tokens(xd, dtype), w.reshape(C, 9).t().contiguous().cuda(), s.cuda(), t.cuda(), 2, 13, 17, dil)
         assert rel_err(from_tokens(got, 2, 13, 17), ref)[0] < (1e-6 if dtype == torch.float32 else 8e-3), dil
+    # wide maps take the comb kernel (4 outputs per thread, one dilation apart): ragged width, every dilation, column window
+    xw = _q(_gen((2, C, 21, 77), 13), dtype)
+    for dil in (1, 6, 12, 18):
+        ref = F.relu(F.conv2d(xw, w, None, padding=dil, dilation=dil, groups=C) * s[None, :, None, None] + t[None, :, None, None])
+        buf = torch.zeros((2 * 21 * 77, 3 * C), dtype=dtype, device="cuda")
+        ops.dwconv3x3(to_tokens(xw, dtype), w.reshape(C, 9).t().contiguous().cuda(), s.cuda(), t.cuda(), 2, 21, 77, dil,
+                      out=buf[:, C:2 * C])
+        assert rel_err(from_tokens(buf[:, C:2 * C], 2, 21, 77), ref)[0] < (1e-6 if dtype == torch.float32 else 8e-3), dil
+        assert buf[:, :C].abs().max().item() == 0 and buf[:, 2 * C:].abs().max().item() == 0
     # tanh gates (prompt / time conditioning) with the batch repeat
     a1, x1, a2, x2 = torch.rand(1, 77, 768), _gen((1, 77, 768), 7), torch.rand(1, 77, 768), _gen((1, 77, 768), 8)
     g = ops.tanh_gate(x1.cuda(), a1.cuda(), x2.cuda(), a2.cuda(), repeat=3).cpu()
