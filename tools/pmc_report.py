@@ -14,15 +14,18 @@ import sys
 
 
 def bench_name(k):
-    dt = lambda s: "_bf16" if s == "DF16b" else "_f32"
-    m = re.search(r"conv3x3_halo_(dma_)?kernelI(DF16b|f)Li(\d+)E", k)
+    dt = lambda s: {"DF16b": "_bf16", "DF16_": "_f16"}.get(s, "_f32")
+    m = re.search(r"conv3x3_h16_kernelI(DF16b|DF16_|f)Li(\d+)E", k)
+    if m:
+        return f"conv3x3_h16_x{m.group(2)}{dt(m.group(1))}"
+    m = re.search(r"conv3x3_halo_(dma_)?kernelI(DF16b|DF16_|f)Li(\d+)E", k)
     if m:
         return f"conv3x3_halo_{m.group(1) or ''}x{m.group(3)}{dt(m.group(2))}"
-    m = re.search(r"igemm_(glds_)?kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E", k)
+    m = re.search(r"igemm_(glds_)?kernelI(DF16b|DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)E", k)
     if m:
         deep = "d" if (not m.group(1) and m.group(3) == "64" and m.group(5) == "8") else ""
         return f"igemm_{m.group(1) or ''}{m.group(3)}x{m.group(4)}{deep}{dt(m.group(2))}"
-    m = re.search(r"(splitk_reduce|gn_apply|gn_stats|layernorm|softmax_rows|image_to_im2col)_kernelI(DF16b|f)", k)
+    m = re.search(r"(splitk_reduce|gn_apply|gn_stats|layernorm|softmax_rows|image_to_im2col)_kernelI(DF16b|DF16_|f)", k)
     if m:
         return m.group(1) + dt(m.group(2))
     return None
