@@ -139,34 +139,78 @@ __device__ __forceinline__ void h16_epilogue_lds(const IgemmP& p, f32x4 (&acc)[M
     const bool want_stats = p.stats != nullptr;
     const int nb = n0 + wn * (BN / 2) + fg * 4;
     float* red = reinterpret_cast<float*>(lds + 256 * ROW);
+#ifdef H16_STAMPS
+    const bool stamp_on = blockIdx.x == gridDim.x / 2 + 1 && blockIdx.z == 0 && tid == 0;
+#endif
+    H16_STAMP(2000);
+    // Every optional piece sits behind a block-uniform branch around its own loop: written as per-element conditions the
+    // compiler turned them into selects (v_max + v_cndmask per value for the optional ReLU, masks on every statistic) and
+    // the epilogue issued ~2 800 VALU instructions, 16 k clocks next to a co-resident block (in-kernel stamps).
+    const bool full = __builtin_amdgcn_readfirstlane((py0 + H16_T <= p.OH && px0 + H16_T <= p.OW && n0 + BN <= p.N) ? 1 : 0) != 0;
     f32x4 cs[NI], cq[NI], add[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     epilogue_consts<NI>(p, nb, b, add);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int oy = py0 + wm * MI + i, ox = px0 + frow;
-        const bool inside = oy < p.OH && ox < p.OW;
-        const int m = (b * p.OH + oy) * p.OW + ox;
-        f32x4 r[NI];
-        if (p.residual && inside) {
-            const T* rp = reinterpret_cast<const T*>(p.residual) + (size_t)m * p.ldr + nb;
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) r[j] = (nb + 16 * j < p.N) ? load4<T>(rp + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        char* row = lds + ((wm * MI + i) * 16 + frow) * ROW + (wn * (BN / 2) + fg * 4) * (int)sizeof(T);
+        for (int j = 0; j < NI; ++j) acc[i][j] += add[j];
+    if (p.residual) {
+        const T* rbase = reinterpret_cast<const T*>(p.residual) + nb;
+        if (full) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            f32x4 v = acc[i][j] + add[j];
-            if (p.residual && inside) v += r[j];
-            if (p.epilogue == MADM_EPI_RELU) {
-                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            for (int i = 0; i < MI; ++i) {
+                const T* rp = rbase + (size_t)((b * p.OH + py0 + wm * MI + i) * p.OW + px0 + frow) * p.ldr;
+                f32x4 r[NI];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) r[j] = load4<T>(rp + 16 * j);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] += r[j];
             }
-            store4<T>(reinterpret_cast<T*>(row + j * 16 * (int)sizeof(T)), v);
-            if (want_stats && inside && nb + 16 * j < p.N) { cs[j] += v; cq[j] += v * v; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int oy = py0 + wm * MI + i, ox = px0 + frow;
+                if (oy < p.OH && ox < p.OW) {
+                    const T* rp = rbase + (size_t)((b * p.OH + oy) * p.OW + ox) * p.ldr;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        if (nb + 16 * j < p.N) acc[i][j] += load4<T>(rp + 16 * j);
+                }
+            }
         }
     }
+    if (p.epilogue == MADM_EPI_RELU) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                f32x4& v = acc[i][j];
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        char* row = lds + ((wm * MI + i) * 16 + frow) * ROW + (wn * (BN / 2) + fg * 4) * (int)sizeof(T);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) store4<T>(reinterpret_cast<T*>(row + j * 16 * (int)sizeof(T)), acc[i][j]);
+    }
+    H16_STAMP(2001);
     if (want_stats) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) { cs[j] += acc[i][j]; cq[j] += acc[i][j] * acc[i][j]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const bool inside = py0 + wm * MI + i < p.OH && px0 + frow < p.OW;
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    if (inside && nb + 16 * j < p.N) { cs[j] += acc[i][j]; cq[j] += acc[i][j] * acc[i][j]; }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
 #pragma unroll
@@ -181,7 +225,9 @@ __device__ __forceinline__ void h16_epilogue_lds(const IgemmP& p, f32x4 (&acc)[M
             }
         }
     }
+    H16_STAMP(2002);
     __syncthreads();
+    H16_STAMP(2003);
     constexpr int CPR = BN * (int)sizeof(T) / 16;             // 16-byte chunks per pixel row of the tile
 #pragma unroll 4
     for (int c = tid; c < 256 * CPR; c += 256) {
@@ -193,12 +239,14 @@ __device__ __forceinline__ void h16_epilogue_lds(const IgemmP& p, f32x4 (&acc)[M
             *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.out) + (size_t)((b * p.OH + oy) * p.OW + ox) * p.ldo + n) = v;
         }
     }
+    H16_STAMP(2004);
     if (want_stats) {
         for (int c = tid; c < 2 * BN; c += 256) {
             const int n = n0 + (c >> 1);
             if (n < p.N) atomicAdd(p.stats + ((size_t)b * p.N + n0) * 2 + c, (double)red[c] + (double)red[2 * BN + c]);
         }
     }
+    H16_STAMP(2005);
 }
 
 template <typename T, int BN, bool FUSE, bool WIDE>
@@ -285,6 +333,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, int
         }                                                                                               \
     }
     // GroupNorm(+act) of the landed chunk, in place: thread = (pixel (tid >> 3) + 32 i, global chunk tid & 7)
+#define H16_TRANSFORM_LOOP(ACT)                                                                         \
+        _Pragma("unroll") for (int i = 0; i < TP; ++i) {                                                \
+            const int h_ = tp_ + 32 * i;                                                                \
+            const int hy_ = h_ / H16_W, hx_ = h_ - hy_ * H16_W;                                         \
+            const int iy_ = py0 - 1 + hy_, ix_ = px0 - 1 + hx_;                                         \
+            if (h_ < H16_PIX && (unsigned)iy_ < (unsigned)p.IH && (unsigned)ix_ < (unsigned)p.IW) {     \
+                uint4* q_ = reinterpret_cast<uint4*>(smem_raw + h_ * 128 + ((cpos_ ^ (hx_ & 7)) * 16));  \
+                const u32x4 v_ = __builtin_bit_cast(u32x4, *q_);                                        \
+                *q_ = __builtin_bit_cast(uint4, h16_gn_act<T, EPC>(v_, sc_, sh_, ACT));                 \
+            }                                                                                           \
+        }
 #define H16_TRANSFORM(ck)                                                                               \
     {                                                                                                   \
         const int cpos_ = tid & 7;                                                                      \
@@ -316,16 +375,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, int
         asm volatile("" : "+v"(tp_));                                                                   \
         /* plain LDS accesses: no DMA is in flight during this pass, so the compiler may schedule them freely (the pass is */ \
         /* VALU-bound: ~11 chunks x ~90 instructions per thread; batching the LDS round trips changed nothing)            */ \
-        _Pragma("unroll") for (int i = 0; i < TP; ++i) {                                                \
-            const int h_ = tp_ + 32 * i;                                                                \
-            const int hy_ = h_ / H16_W, hx_ = h_ - hy_ * H16_W;                                         \
-            const int iy_ = py0 - 1 + hy_, ix_ = px0 - 1 + hx_;                                         \
-            if (h_ < H16_PIX && (unsigned)iy_ < (unsigned)p.IH && (unsigned)ix_ < (unsigned)p.IW) {     \
-                uint4* q_ = reinterpret_cast<uint4*>(smem_raw + h_ * 128 + ((cpos_ ^ (hx_ & 7)) * 16));  \
-                const u32x4 v_ = __builtin_bit_cast(u32x4, *q_);                                        \
-                *q_ = __builtin_bit_cast(uint4, h16_gn_act<T, EPC>(v_, sc_, sh_, p.act));               \
-            }                                                                                           \
-        }                                                                                               \
+        /* the activation switch sits OUTSIDE the pass (three copies of the loop): tested per pair inside it, it cost 120   */ \
+        /* scalar branches + 264 s_nop per thread and chunk                                                               */ \
+        if (p.act == 1) { H16_TRANSFORM_LOOP(1) } else if (p.act == 2) { H16_TRANSFORM_LOOP(2) } else { H16_TRANSFORM_LOOP(0) } \
     }
     // weight stream: tile s = (chunk lck, tap ltap) goes to ring slot s & 1
     int lck = ck0, ltap = 0, lslot = 0;

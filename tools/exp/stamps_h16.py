@@ -34,6 +34,11 @@ assert lib.madm_debug_read_h16_stamps(buf, n) == 0
 t0 = buf[0]
 print(f"cin {cin} cout {cout} {hw}x{hw} gn {gn}: set-up {buf[1] - t0}, first DMAs issued +{buf[2] - buf[1]}, fold +{buf[3] - buf[2]}; "
       f"loop end at {buf[4] - t0}, epilogue {buf[5] - buf[4]}, total {buf[5] - t0}")
+big = (ctypes.c_ulonglong * 2008)()
+assert lib.madm_debug_read_h16_stamps(big, 2008) == 0
+e = big[2000:2006]
+print(f"epilogue (LDS-transposed): enter +{e[0] - buf[4]}, values -> LDS {e[1] - e[0]}, channel sums {e[2] - e[1]}, barrier {e[3] - e[2]}, "
+      f"16-byte stores issued {e[4] - e[3]}, statistics atomics {e[5] - e[4]}")
 i = 8
 for ck in range(nck):
     a, b, c = buf[i], buf[i + 1], buf[i + 2]
