@@ -20,7 +20,26 @@ import os
 import sys
 import time
 
-import torch
+
+
+def _early_int_flag(name, default):
+    """Flags that must act before the HIP runtime starts (it reads its environment once)."""
+    for i, a in enumerate(sys.argv):
+        if a == name and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+        if a.startswith(name + "="):
+            return int(a.split("=", 1)[1])
+    return default
+
+
+# The staged pipeline below keeps 1 + --pipeline streams busy; ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES
+# hardware queues (default 4), and streams that share a queue serialise (measured: 4 UNet graphs side by side take
+# 4.27 ms each with 4 queues, 3.47 ms with 8 -- profiles/round2_unet_concurrency.txt).
+HW_QUEUES = _early_int_flag("--hw-queues", 8)
+if HW_QUEUES > 0:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(HW_QUEUES))
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -49,6 +68,13 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the graph executables are replayed on, round-robin: with 2, consecutive steps overlap "
                          "(the MFMA-bound VAE encoder of step k+1 fills the CUs the latency-bound UNet of step k leaves idle)")
+    ap.add_argument("--pipeline", type=int, default=3,
+                    help="extract workload: UNet streams of the staged pipeline (madm_amd/pipeline.py: every batch's VAE "
+                         "encoder on one stream, its UNet on one of K streams, so K UNets of consecutive batches run side by "
+                         "side and the next encoder slides under them; K + 1 batches in flight).  0 = whole-forward graphs "
+                         "round-robin on --streams streams (the round-1 launch)")
+    ap.add_argument("--hw-queues", type=int, default=8,
+                    help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime default of 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lora", action="store_true", help="enable one r=8 LoRA adapter (north_star variant)")
@@ -302,34 +328,69 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
     if rank == 0 and not args.no_kernel_profile:
         prof, event_overhead_us = kernel_profile(model, call)
 
-    fork = join = (lambda: None)
-    if args.no_graph:
-        def step():
-            return model(*call)
-    else:
+    join = (lambda ts: None)
+    first_stream = None
+    staged = args.workload == "extract" and args.pipeline > 0 and not args.no_graph
+    graphs, outs, streams = [], [], [None]
+
+    def capture_whole_forward(nstreams, nexec):
+        """Whole-forward hipGraph executables, round-robin on ``nstreams`` streams."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             model(*call)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        nexec = max(1, args.graphs, args.streams)
-        streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))] if args.streams > 1 else [None]
-        graphs, outs = [], []
+        sts = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams >= 1 else [None]
+        gs, os_ = [], []
         for i in range(nexec):
             g = torch.cuda.CUDAGraph()
-            st = streams[i % len(streams)]
+            st = sts[i % len(sts)]
             if st is not None:
                 st.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st):
                     model(*call)          # sizes this stream's split-K workspace outside the capture
                 st.synchronize()
                 with torch.cuda.graph(g, stream=st):
-                    outs.append(model(*call))
+                    os_.append(model(*call))
             else:
                 with torch.cuda.graph(g):
-                    outs.append(model(*call))
-            graphs.append(g)
+                    os_.append(model(*call))
+            gs.append(g)
+        return gs, os_, sts
+
+    def serial_reference(g, st):
+        # reference point, outside the timed region: the same K steps strictly one after the other (one executable,
+        # one stream) -- the latency of a step; the timed region overlaps consecutive steps on several streams
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                g.replay()
+            a.record()
+            for _ in range(args.steps):
+                g.replay()
+            b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / args.steps
+
+    if args.no_graph:
+        def step():
+            return model(*call)
+    elif staged:
+        # the pipeline's streams are the FIRST streams this process creates: four busy streams run side by side only when
+        # they sit on four different hardware pipes, and the runtime hands queues out in creation order (measured:
+        # encoder + 3 UNet streams 6.3 ms per step, the same with one more stream on the encoder's pipe 7.8 ms --
+        # profiles/round2_unet_concurrency.txt); the whole-forward executable of the serial_* reference point is built
+        # after the timed region
+        from madm_amd.pipeline import StagedExtractor
+        pipe = StagedExtractor(ldm, call[0], unet_streams=args.pipeline)
+
+        def step():
+            return pipe.submit()[0]
+        join, first_stream = pipe.join, pipe.s_enc
+    else:
+        graphs, outs, streams = capture_whole_forward(args.streams if args.streams > 1 else 0,
+                                                      max(1, args.graphs, args.streams))
         turn = [0]
 
         def step():
@@ -343,48 +404,52 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
                     graphs[i].replay()
             return outs[i]
 
-        def fork():      # the side streams start after everything queued on the timing stream
-            for st in streams:
-                if st is not None:
-                    st.wait_stream(torch.cuda.current_stream())
+        first_stream = streams[0]
 
-        def join():      # ... and the timing stream's closing event waits for all of them
+        def join(ts):      # the timing stream's closing event waits for all of them
             for st in streams:
                 if st is not None:
-                    torch.cuda.current_stream().wait_stream(st)
+                    ts.wait_stream(st)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     serial_ms = None
-    if not args.no_graph and args.streams > 1:
-        # reference point, outside the timed region: the same K steps strictly one after the other (one executable,
-        # one stream) -- the latency of a step; the timed region below overlaps consecutive steps on the streams
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        st = streams[0]
-        with torch.cuda.stream(st):
-            a.record()
-            for _ in range(args.steps):
-                graphs[0].replay()
-            b.record()
-        torch.cuda.synchronize()
-        serial_ms = a.elapsed_time(b) / args.steps
+    if not args.no_graph and not staged and args.streams > 1:
+        serial_ms = serial_reference(graphs[0], streams[0])
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # The timed region starts from an idle device (synchronize above) and ends with a device synchronize: no stream waits
+    # on another one at the START.  Round 1 forked the side streams from an event on the legacy null stream; measured
+    # this round, streams that begin with such a cross-stream wait stop running side by side for the whole region
+    # (staged pipeline: 224 images/s forked from the null stream, 294 forked from a stream of its own, 318 without).
+    # device_ms_per_step: from the first stream's first command to a closing event that has waited for every stream.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    bracket = os.environ.get("MADM_BENCH_BRACKET", "1") != "0"
     t0 = time.perf_counter()
-    ev0.record()
-    fork()
+    if bracket:
+        if first_stream is not None:
+            ev0.record(first_stream)
+        else:
+            ev0.record()
     for _ in range(args.steps):
         step()
-    join()
-    ev1.record()
+    if bracket:
+        if first_stream is not None:
+            tstream = torch.cuda.Stream()
+            join(tstream)
+            ev1.record(tstream)
+        else:
+            ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
         elapsed = mdist.max_over_ranks(elapsed, dist, device)
+    if staged:
+        gs_, _, sts_ = capture_whole_forward(1, 1)
+        serial_ms = serial_reference(gs_[0], sts_[0])
 
     if rank == 0:
         images = args.batch * world * args.steps
@@ -414,14 +479,18 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
                          "batched as B=3 through VAE enc -> UNet -> VAE dec -> projections, window features averaged, "
                          "DAFormer head @512x1024, K=9)")),
                        "global_batch": args.batch * world, "parallelism": f"replicas x{world} (no collectives)",
-                       "launch": "eager" if args.no_graph else ("hipGraph replay, 1 stream: one batch in flight"
+                       "launch": "eager" if args.no_graph else
+                       (f"staged hipGraph pipeline (madm_amd/pipeline.py): VAE-encoder graphs on 1 stream, UNet graphs on "
+                        f"{args.pipeline} streams, up to {args.pipeline + 1} batches ({(args.pipeline + 1) * args.batch} images) in "
+                        f"flight, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}; serial_* = whole-forward "
+                        "graph, one batch in flight") if staged else ("hipGraph replay, 1 stream: one batch in flight"
                                                                 if args.streams <= 1 else
                                                                 f"hipGraph replay on {args.streams} streams: {args.streams} "
                                                                 f"batches ({args.streams * args.batch} images) in flight, "
                                                                 "consecutive steps overlap; serial_* = one batch in flight"),
                        "range_check": "the reference's per-call input-range assert (ldm_diffusers.py:147, a host sync) ran "
                                       "once before the timed region; its min/max probe kernel still runs every step"},
-            "device_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 4),
+            "device_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 4) if bracket else None,
             "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
             "serial_images_per_s_per_gpu": None if serial_ms is None else round(args.batch / serial_ms * 1e3, 3),
             "whole_path_roofline_frac": round(value / world * alg / (peak * 1e12), 4),

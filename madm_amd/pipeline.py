@@ -1,0 +1,89 @@
+"""Throughput launch strategy for LdmRocm.forward: the two stages of the path as separate hipGraph executables on
+separate HIP streams.
+
+Stage 1 (``LdmRocm._stage_encode``: normalise -> vae_encoder -> timestep draw -> add_noise, ldm_diffusers.py:143-163) is
+MFMA-bound and fills the chip on its own; stage 2 (``_stage_unet``: diffusion_unet + the tap hand-over, :165-217) at
+bs = 2 is launch / latency-bound and leaves most CUs idle.  So consecutive batches are overlapped
+like this: every batch's encoder runs on ONE stream (encoders never overlap each other: nothing to gain), its UNet on
+one of ``unet_streams`` streams after the encoder's event, so up to ``unet_streams`` UNets of different batches run side
+by side and the next encoder slides under them.  Each in-flight batch owns a hand-over slot (latents, timesteps) and its
+own output tensors; a slot's encoder waits until the slot's previous UNet has finished.
+
+Same kernels, same per-batch results as ``LdmRocm.forward`` (tests/test_parity_gpu.py::test_staged_pipeline_matches_forward);
+only the order in which the GPU sees the launches changes.
+"""
+import torch
+
+from . import ops
+
+
+class StagedExtractor:
+    def __init__(self, ldm, batched_inputs, unet_streams=3, **kwargs):
+        assert unet_streams >= 1
+        self.ldm = ldm
+        self.k = int(unet_streams)
+        dev = batched_inputs['img'].device
+        self.s_enc = torch.cuda.Stream(device=dev)
+        self.s_unet = [torch.cuda.Stream(device=dev) for _ in range(self.k)]
+        self.enc_graphs, self.unet_graphs, self.slots, self.outs = [], [], [], []
+        cur = torch.cuda.current_stream(dev)
+        with torch.no_grad():
+            for j in range(self.k):
+                self.s_enc.wait_stream(cur)
+                with torch.cuda.stream(self.s_enc):
+                    ldm._stage_encode(batched_inputs)          # sizes this stream's workspaces outside the capture
+                self.s_enc.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.s_enc):
+                    st = ldm._stage_encode(batched_inputs)
+                self.enc_graphs.append(g)
+                self.slots.append(st)
+            for j in range(self.k):
+                s = self.s_unet[j]
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    ops.ARENA.reset(dev)
+                    ldm._stage_unet(self.slots[j], batched_inputs, **kwargs)
+                s.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    ops.ARENA.reset(dev)                       # the statistics arena of this stage: zeroed inside the graph
+                    self.outs.append(ldm._stage_unet(self.slots[j], batched_inputs, **kwargs))
+                self.unet_graphs.append(g)
+        torch.cuda.synchronize(dev)
+        self.encoded = [torch.cuda.Event() for _ in range(self.k)]
+        self.done = [torch.cuda.Event() for _ in range(self.k)]
+        self.turn = 0
+
+    @property
+    def streams(self):
+        return [self.s_enc, *self.s_unet]
+
+    def submit(self):
+        """Enqueues one batch; returns (outputs, event): the slot's output tensors are valid once ``event`` has fired and
+        stay so until the slot comes round again (``unet_streams`` submits later)."""
+        j = self.turn % self.k
+        first = self.turn < self.k
+        self.turn += 1
+        with torch.cuda.stream(self.s_enc):
+            if not first:
+                self.s_enc.wait_event(self.done[j])            # the slot's hand-over buffers are free again
+            self.enc_graphs[j].replay()
+            self.encoded[j].record(self.s_enc)
+        s = self.s_unet[j]
+        with torch.cuda.stream(s):
+            s.wait_event(self.encoded[j])
+            self.unet_graphs[j].replay()
+            self.done[j].record(s)
+        return self.outs[j], self.done[j]
+
+    def fork(self, stream=None):
+        """The pipeline's streams start after everything queued on ``stream`` (default: the current one)."""
+        stream = stream or torch.cuda.current_stream()
+        for s in self.streams:
+            s.wait_stream(stream)
+
+    def join(self, stream=None):
+        stream = stream or torch.cuda.current_stream()
+        for s in self.streams:
+            stream.wait_stream(s)

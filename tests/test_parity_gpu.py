@@ -145,6 +145,40 @@ def test_batch_invariance_and_determinism(extractor):
         assert l2 < 2.5e-2, f"B=2 vs B=1: {e:.2e} {l2:.2e}"
 
 
+
+def test_staged_pipeline_matches_forward(extractor):
+    """madm_amd.pipeline.StagedExtractor (bench.py's launch strategy: encoder graphs on one stream, UNet graphs on K
+    streams, K + 1 batches in flight) must hand back exactly what LdmRocm.forward returns for the same batch, for every
+    slot and on every round."""
+    from madm_amd.pipeline import StagedExtractor
+    case = dict(CASES["small_t0"])
+    images, cond_inputs, cond_emb, _, _ = make_inputs(**case)
+    m = extractor
+    m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = torch.float16
+    inputs = {"img": images.repeat(2, 1, 1, 1).cuda(), "cond_inputs": cond_inputs.repeat(2, 1, 1).cuda(),
+              "cond_emb": cond_emb.repeat(2, 1, 1).cuda()}
+    with torch.no_grad():
+        want = [f.clone() for f in m(inputs, "rgb")]
+        torch.cuda.synchronize()
+        keep = m.check_input_range
+        m.check_input_range = False
+        try:
+            pipe = StagedExtractor(m, inputs, unet_streams=3)
+            pipe.fork()
+            got = []
+            for step in range(7):                       # every slot is reused at least once
+                outs, done = pipe.submit()
+                done.synchronize()
+                got.append([f.clone() for f in outs])
+            pipe.join()
+            torch.cuda.synchronize()
+        finally:
+            m.check_input_range = keep
+    for step, feats in enumerate(got):
+        assert len(feats) == len(want)
+        for a, b in zip(feats, want):
+            assert torch.equal(a, b), f"step {step}: staged pipeline differs from forward()"
+
 def test_helper_functions_match_reference_signatures(extractor):
     """vae_encoder / add_noise / diffusion_unet keep the reference's call signatures
     (ldm_diffusers.py:283,349,454) and reproduce the golden intermediates when chained by hand."""

@@ -10,12 +10,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from madm_amd import ops
 from madm_amd._lib import lib
 
-cin, cout, hw, gn = (int(x) for x in (sys.argv[1:5] + ["128", "128", "512", "0"][len(sys.argv) - 1:]))
+cin, cout, hw, gn, res = (int(x) for x in (sys.argv[1:6] + ["128", "128", "512", "0", "0"][len(sys.argv) - 1:]))
 B = 2
 DT = torch.float16 if os.environ.get("DT") == "f16" else torch.bfloat16
 x = torch.randn((B * hw * hw, cin), device="cuda").to(DT)
 w = (torch.randn((cout, 9 * cin), device="cuda") / math.sqrt(9 * cin)).to(DT)
 bias = torch.randn(cout, device="cuda")
+resid = torch.randn((B * hw * hw, cout), device="cuda").to(DT) if res else None
 g = None
 st = torch.zeros((B, cout, 2), dtype=torch.float64, device="cuda")
 if gn:
@@ -24,7 +25,7 @@ if gn:
     g = ([sums], torch.rand(cin, device="cuda") + 0.5, torch.randn(cin, device="cuda") * 0.1, 32, 1e-5, True)
 lib.madm_debug_set_conv_tile(12)
 for _ in range(3):
-    ops.conv2d(x, w, B, hw, hw, N=cout, KH=3, KW=3, pad_t=1, pad_l=1, bias=bias, gn=g, splitk=1, stats=st)
+    ops.conv2d(x, w, B, hw, hw, N=cout, KH=3, KW=3, pad_t=1, pad_l=1, bias=bias, gn=g, splitk=1, stats=st, residual=resid)
 torch.cuda.synchronize()
 nck = cin // 64
 n = 8 + nck * (3 + 36)
@@ -32,7 +33,7 @@ buf = (ctypes.c_ulonglong * n)()
 lib.madm_debug_read_h16_stamps.restype = ctypes.c_int
 assert lib.madm_debug_read_h16_stamps(buf, n) == 0
 t0 = buf[0]
-print(f"cin {cin} cout {cout} {hw}x{hw} gn {gn}: set-up {buf[1] - t0}, first DMAs issued +{buf[2] - buf[1]}, fold +{buf[3] - buf[2]}; "
+print(f"cin {cin} cout {cout} {hw}x{hw} gn {gn} residual {res}: set-up {buf[1] - t0}, first DMAs issued +{buf[2] - buf[1]}, fold +{buf[3] - buf[2]}; "
       f"loop end at {buf[4] - t0}, epilogue {buf[5] - buf[4]}, total {buf[5] - t0}")
 big = (ctypes.c_ulonglong * 2008)()
 assert lib.madm_debug_read_h16_stamps(big, 2008) == 0

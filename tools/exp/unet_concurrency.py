@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--rounds", type=int, default=20)
     ap.add_argument("--kmax", type=int, default=4)
+    ap.add_argument("--dummy", type=int, default=0, help="idle streams created (and used once) before the pipeline's")
+    ap.add_argument("--only", default="", help="comma list of k: only the single-encoder-stream pipeline for these k")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
@@ -38,6 +40,11 @@ def main():
         torch.cuda.synchronize()
         model.check_input_range = False
         K = args.kmax
+        dummies = [torch.cuda.Stream() for _ in range(args.dummy)]
+        for d in dummies:
+            with torch.cuda.stream(d):
+                torch.zeros(4, device=dev)
+        torch.cuda.synchronize()
         s_enc = torch.cuda.Stream()
         s_un = [torch.cuda.Stream() for _ in range(K)]
 
@@ -85,7 +92,8 @@ def main():
         t_enc = timed(enc_only, R)
         print(f"encoder stage alone: {t_enc:.3f} ms per batch", flush=True)
 
-        for k in range(1, K + 1):
+        only = [int(x) for x in args.only.split(",") if x]
+        for k in ([] if only else range(1, K + 1)):
             def un_k():
                 for r in range(R):
                     for j in range(k):
@@ -97,7 +105,7 @@ def main():
                   f"{2e3 / (t_enc + t):.1f} images/s if the encoder runs exclusively", flush=True)
 
         # staged pipeline
-        for k in range(1, K + 1):
+        for k in (only or range(1, K + 1)):
             evs = [torch.cuda.Event() for _ in range(K)]
             done = [torch.cuda.Event() for _ in range(K)]
 
@@ -116,6 +124,31 @@ def main():
             pipe()
             t = timed(pipe, R)
             print(f"pipeline, encoder stream + {k} UNet streams: {t:.3f} ms per step = {2e3 / t:.1f} images/s", flush=True)
+        if only:
+            return
+
+        # two encoder streams + k UNet streams
+        s_enc2 = torch.cuda.Stream()
+        for k in range(2, K + 1):
+            evs = [torch.cuda.Event() for _ in range(K)]
+            done = [torch.cuda.Event() for _ in range(K)]
+
+            def pipe2():
+                for r in range(R):
+                    j = r % k
+                    se = s_enc if (r & 1) == 0 else s_enc2
+                    with torch.cuda.stream(se):
+                        if r >= k:
+                            se.wait_event(done[j])
+                        enc_graphs[j].replay()
+                        evs[j].record(se)
+                    with torch.cuda.stream(s_un[j]):
+                        s_un[j].wait_event(evs[j])
+                        un_graphs[j].replay()
+                        done[j].record(s_un[j])
+            pipe2()
+            t = timed(pipe2, R)
+            print(f"pipeline, 2 encoder streams + {k} UNet streams: {t:.3f} ms per step = {2e3 / t:.1f} images/s", flush=True)
 
         # batched-phase schedule: k encoders back to back, then k UNets side by side, phases separated by events
         for k in range(2, K + 1):
