@@ -65,9 +65,10 @@ def parse():
     ap.add_argument("--graphs", type=int, default=1,
                     help="graph executables replayed round-robin (measured: 1, 2 and 3 give the same step time, the "
                          "host-side launch of a replay already overlaps the previous one)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the graph executables are replayed on, round-robin: with 2, consecutive steps overlap "
-                         "(the MFMA-bound VAE encoder of step k+1 fills the CUs the latency-bound UNet of step k leaves idle)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="whole-forward mode (eval / slide workloads, or --pipeline 0): HIP streams the graph executables are "
+                         "replayed on, round-robin, so consecutive steps overlap (measured eval: 71.6 / 86.6 / 92.9 images/s on "
+                         "1 / 2 / 3 streams; four hardware pipes serve the queues, a fourth stream loses again)")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="extract workload: UNet streams of the staged pipeline (madm_amd/pipeline.py: every batch's VAE "
                          "encoder on one stream, its UNet on one of K streams, so K UNets of consecutive batches run side by "
@@ -328,8 +329,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
     if rank == 0 and not args.no_kernel_profile:
         prof, event_overhead_us = kernel_profile(model, call)
 
-    join = (lambda ts: None)
-    first_stream = None
+    first_stream = None      # set when the steps run on streams of their own
     staged = args.workload == "extract" and args.pipeline > 0 and not args.no_graph
     graphs, outs, streams = [], [], [None]
 
@@ -387,7 +387,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
 
         def step():
             return pipe.submit()[0]
-        join, first_stream = pipe.join, pipe.s_enc
+        first_stream = pipe.s_enc
     else:
         graphs, outs, streams = capture_whole_forward(args.streams if args.streams > 1 else 0,
                                                       max(1, args.graphs, args.streams))
@@ -406,11 +406,6 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
 
         first_stream = streams[0]
 
-        def join(ts):      # the timing stream's closing event waits for all of them
-            for st in streams:
-                if st is not None:
-                    ts.wait_stream(st)
-
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -420,28 +415,21 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    # The timed region starts from an idle device (synchronize above) and ends with a device synchronize: no stream waits
-    # on another one at the START.  Round 1 forked the side streams from an event on the legacy null stream; measured
-    # this round, streams that begin with such a cross-stream wait stop running side by side for the whole region
-    # (staged pipeline: 224 images/s forked from the null stream, 294 forked from a stream of its own, 318 without).
-    # device_ms_per_step: from the first stream's first command to a closing event that has waited for every stream.
+    # The timed region starts from an idle device (synchronize above) and ends with a device synchronize; `value` is the
+    # wall clock between them.  With several streams NOTHING else is enqueued in the region -- no fork from / join into a
+    # timing stream, no timing events: every variant of a device-side bracket measured this round cost throughput (staged
+    # pipeline, same box: 303 images/s bare, 274 with an idle timing stream that joins at the end, 217 forked from and
+    # joined into the legacy null stream as in round 1; a queue that sits on a wait keeps its hardware pipe busy and the
+    # pipe's other queue -- one of the four working streams -- starves).  device_ms_per_step exists for one stream only.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    bracket = os.environ.get("MADM_BENCH_BRACKET", "1") != "0"
+    single = first_stream is None
     t0 = time.perf_counter()
-    if bracket:
-        if first_stream is not None:
-            ev0.record(first_stream)
-        else:
-            ev0.record()
+    if single:
+        ev0.record()
     for _ in range(args.steps):
         step()
-    if bracket:
-        if first_stream is not None:
-            tstream = torch.cuda.Stream()
-            join(tstream)
-            ev1.record(tstream)
-        else:
-            ev1.record()
+    if single:
+        ev1.record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -490,7 +478,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
                                                                 "consecutive steps overlap; serial_* = one batch in flight"),
                        "range_check": "the reference's per-call input-range assert (ldm_diffusers.py:147, a host sync) ran "
                                       "once before the timed region; its min/max probe kernel still runs every step"},
-            "device_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 4) if bracket else None,
+            "device_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 4) if single else None,
             "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
             "serial_images_per_s_per_gpu": None if serial_ms is None else round(args.batch / serial_ms * 1e3, 3),
             "whole_path_roofline_frac": round(value / world * alg / (peak * 1e12), 4),
