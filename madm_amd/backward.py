@@ -51,7 +51,7 @@ def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None, upsample=Fa
         grads["weight"] = packing.unpack_conv_weight_grad(dwp[:conv.out_channels], conv.in_channels, k, k, kt,
                                                           splits=splits)
         if conv.bias is not None:
-            grads["bias"] = _colsum_per_image(dout, x.B, OH * OW).sum(0)[:conv.out_channels]
+            grads["bias"] = ops.colsum(dout, 1, x.B * OH * OW)[0, :conv.out_channels]
     dx = None
     if need_dx:
         def build_wt():

@@ -363,6 +363,7 @@ class _TrainStepFn(torch.autograd.Function):
         g = {n: (go if go is not None else None) for n, go in zip(names, gouts)}
         acc = {}
         touched = set()
+        early = set()
         sink = getattr(model, "grad_sink", None)     # train.MadmTrainer: gradients go straight into its flat buffer and
         passes = []                                  # finished spans are all-reduced while the backward still runs
         dtype = st["rec_s"]["keep"]["dtype"]
@@ -376,25 +377,32 @@ class _TrainStepFn(torch.autograd.Function):
             def add(p, v, last=last):
                 v = v.reshape(p.shape)
                 touched.add(id(p))
-                cur = acc.pop(id(p), None) if (last and sink is not None) else acc.get(id(p))
-                tot = v if cur is None else cur + v
-                if last and sink is not None:
-                    sink.final(p, tot)               # a parameter shared by several producers (prompt gates) arrives twice:
-                else:                                # the sink accumulates
-                    acc[id(p)] = tot
+                if sink is not None:                 # straight into the trainer's flat buffer (batched adds); the LAST
+                    if last:                         # pass marks the parameter's span as finished
+                        early.discard(id(p))
+                        sink.final(p, v)
+                    else:
+                        early.add(id(p))
+                        sink.accumulate(p, v)
+                    return
+                cur = acc.get(id(p))
+                acc[id(p)] = v if cur is None else cur + v
 
             dlogits = crit.ce_backward(ctxs[ce_name], g[ce_name], dtype) if g.get(ce_name) is not None else None
             dsample = None
             if dec_name in ctxs and g.get(dec_name) is not None:
                 dsample = crit.decoder_loss_backward(ctxs[dec_name], g[dec_name])
+            ops.GRAD_ZEROS.reset(dlogits.device if dlogits is not None else dsample.device)   # one memset per pass
             model._backward_pass(rec, dlogits, dsample, add)
+            if sink is not None:
+                sink.flush()
+        ops.GRAD_ZEROS.drop()
         st["rec_s"] = st["rec_t"] = None       # free the tapes
         model.last_grad_param_ids = touched    # torch.optim.AdamW skips parameters whose grad is None
         if sink is not None:
-            for p in params:                   # gradients only the first pass produced
-                v = acc.pop(id(p), None)
-                if v is not None:
-                    sink.final(p, v)
+            for p in params:                   # gradients only the first pass produced: already added, now finished
+                if id(p) in early:
+                    sink.final(p, None)
             sink.backward_done()
             return (None, None) + (None,) * ctx.n_losses + (None,) * len(params)
         return (None, None) + (None,) * ctx.n_losses + tuple(acc.get(id(p)) for p in params)

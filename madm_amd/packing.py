@@ -34,17 +34,20 @@ def pack_conv_weight(w, dtype, ktile, splits=None):
 
 def unpack_conv_weight_grad(dw, Cin, KH, KW, ktile, splits=None):
     """Inverse of :func:`pack_conv_weight` for the f32 gradient ops.conv2d_wgrad returns:
-    [N, KH*KW*sum(pad(splits))] -> [N, Cin, KH, KW] (the gradient of the padding channels is dropped)."""
+    [N, KH*KW*sum(pad(splits))] -> [N, Cin, KH, KW] (the gradient of the padding channels is dropped).  A VIEW of ``dw``
+    for a single source (the consumer adds it into the parameter's gradient: one strided add instead of copy + add)."""
     N = dw.shape[0]
     if splits is None:
         splits = [Cin]
     cpads = [round_up(c, ktile) for c in splits]
     g = dw.reshape(N, KH, KW, sum(cpads))
+    if len(splits) == 1:
+        return g[..., :splits[0]].permute(0, 3, 1, 2)
     parts, p0 = [], 0
     for c, cp in zip(splits, cpads):
         parts.append(g[..., p0:p0 + c])
         p0 += cp
-    return torch.cat(parts, dim=-1).permute(0, 3, 1, 2).contiguous()
+    return torch.cat(parts, dim=-1).permute(0, 3, 1, 2)
 
 
 def pack_linear_weight(w, dtype, ktile):

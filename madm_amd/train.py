@@ -48,6 +48,7 @@ class MadmTrainer:
         self._index = {id(p): i for i, p in enumerate(self.opt.flat.params)}
         self._final = [False] * len(self.opt.flat.params)
         self._ptr = len(self._final) - 1
+        self._pend_dst, self._pend_src, self._pend_ids = [], [], set()
         self.overlap = dist is not None and dist.get_world_size() > 1
         model.grad_sink = self
         self.reduced_during_backward = 0       # elements whose all-reduce started before the backward returned
@@ -69,9 +70,14 @@ class MadmTrainer:
     def final(self, p, g):
         i = self._index[id(p)]
         assert not self._final[i], "a gradient arrived after its span was handed to the all-reduce"
-        p.grad.add_(g.reshape(p.shape).to(p.grad.dtype))
+        # adds are batched (torch._foreach_add_: one launch per group of same-layout tensors instead of one per tensor --
+        # 1 500 five-microsecond kernels per step); flushed before a span is handed to the all-reduce and at the end
+        if g is not None:
+            self._queue(p, g)
         self._final[i] = True
         if not self.overlap:
+            if len(self._pend_dst) >= 256:
+                self.flush()
             return
         ptr = self._ptr
         while ptr >= 0 and self._final[ptr]:
@@ -79,12 +85,33 @@ class MadmTrainer:
         if ptr != self._ptr:
             lo = self.opt.flat.offsets[ptr + 1]
             if self.reducer.done_lo - lo >= self.reducer.bucket or ptr < 0:   # whole buckets only: few, large messages
+                self.flush()
                 self.reduced_during_backward += self.reducer.done_lo - lo
                 self.reducer.reduce_tail(lo)
             self._ptr = ptr
 
+    def accumulate(self, p, g):
+        """A contribution that is not the parameter's last one this step (the source pass of the training step)."""
+        assert not self._final[self._index[id(p)]]
+        self._queue(p, g)
+        if not self.overlap and len(self._pend_dst) >= 256:
+            self.flush()
+
+    def _queue(self, p, g):
+        if id(p) in self._pend_ids:            # one destination twice in a multi-tensor add would race
+            self.flush()
+        self._pend_ids.add(id(p))
+        self._pend_dst.append(p.grad)
+        self._pend_src.append(g.reshape(p.shape) if g.dtype == p.grad.dtype else g.reshape(p.shape).to(p.grad.dtype))
+
+    def flush(self):
+        if self._pend_dst:
+            torch._foreach_add_(self._pend_dst, self._pend_src)
+            self._pend_dst, self._pend_src = [], []
+            self._pend_ids = set()
+
     def backward_done(self):
-        pass
+        self.flush()
 
     def run_step(self, data):
         """Returns (loss dict of python floats, total gradient norm, stepped)."""
@@ -97,6 +124,7 @@ class MadmTrainer:
         loss_dict = model(data)
         losses = sum(loss_dict.values())
         (losses * self.scale).backward()
+        self.flush()
         ev = None
         if self.overlap and torch.cuda.is_available() and self.opt.flat.grad.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
