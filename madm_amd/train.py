@@ -100,9 +100,13 @@ class MadmTrainer:
     def _queue(self, p, g):
         if id(p) in self._pend_ids:            # one destination twice in a multi-tensor add would race
             self.flush()
+        g = g.reshape(p.shape) if g.dtype == p.grad.dtype else g.reshape(p.shape).to(p.grad.dtype)
+        if not g.is_contiguous():              # permuted view of a 3 x 3 weight gradient: one strided add; a single
+            p.grad.add_(g)                     # such tensor would push the whole multi-tensor call onto its slow path
+            return
         self._pend_ids.add(id(p))
         self._pend_dst.append(p.grad)
-        self._pend_src.append(g.reshape(p.shape) if g.dtype == p.grad.dtype else g.reshape(p.shape).to(p.grad.dtype))
+        self._pend_src.append(g)
 
     def flush(self):
         if self._pend_dst:
