@@ -26,6 +26,8 @@ SHAPES = [
     ("ff out 1280->320", 2, 4096, 1, 1280, 320, 1),
     ("attn proj 1280 (L 256)", 2, 256, 1, 1280, 1280, 1),
     ("ff geglu 1280->10240", 2, 256, 1, 1280, 10240, 1),
+    ("head 1x1 1024->256 @512", 2, 512 * 512, 1, 1024, 256, 1),
+    ("head 3x3 1280->256 @512", 2, 512, 512, 1280, 256, 3),
 ]
 
 
