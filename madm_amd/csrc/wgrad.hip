@@ -27,21 +27,17 @@ struct WgradP {
     unsigned bytes1, bytes2, bytesd;
 };
 
-// SUB: MFMA k-extents staged per step (one barrier per step).  SUB = 1 moved 16 KB and ran 16 MFMAs per wave between two
-// barriers; SUB = 2 halves the barriers / staging round trips per MFMA on the long reductions (the head's and the VAE's
-// 512 x 512 layers: 16 384 pixels-steps), SUB = 1 stays for the UNet's short ones (LDS: 36 / 72 KB, two blocks per CU).
-template <typename T, int SUB>
+template <typename T>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
     constexpr int EPC = TT<T>::EPC;
-    constexpr int PX1 = 4 * EPC;                 // pixels per MFMA k-extent (16-bit 32, f32 16)
-    constexpr int PX = PX1 * SUB;                // pixels per staged step
+    constexpr int PX = 4 * EPC;                  // pixels per K step: one MFMA k-extent (bf16 32, f32 16)
     constexpr int CPR = 128 / EPC;               // 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;               // rows staged per pass of the block
-    constexpr int LI = PX / RPP;                 // passes (2 per k-extent)
+    constexpr int LI = PX / RPP;                 // passes (2)
     constexpr int ROWB = 128 * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);   // padded: transposed reads conflict-free
     constexpr int TILEB = PX * ROWB;
     constexpr unsigned OOB = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) char smem[];     // 4 * TILEB: {dout, A} x 2 stages
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILEB];   // {dout, A} x 2 stages
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave & 1, wc = wave >> 1;
@@ -102,10 +98,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
             }
             ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, offa, 0, 0);
             pm[i] += PX;
-            px[i] += PX;
-            while (px[i] >= p.OW) {
-                px[i] -= p.OW;
-                if (++py[i] == p.OH) { py[i] = 0; ++pb[i]; }
+            if (!p.lin) {   // (a linear layer is OW = 1: the walk below would take PX iterations per step for nothing)
+                px[i] += PX;
+                while (px[i] >= p.OW) {
+                    px[i] -= p.OW;
+                    if (++py[i] == p.OH) { py[i] = 0; ++pb[i]; }
+                }
             }
         }
     };
@@ -133,60 +131,55 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
         if (more) load_step();
         const char* td = smem + (s & 1) * 2 * TILEB;
         const char* ta = td + TILEB;
+        uint4 fd[4], fa[4];
+        if constexpr (sizeof(T) == 2) {
+            const int row = fg * 4 + (fi >> 2), colb = (fi & 3) * 8;
 #pragma unroll
-        for (int sub = 0; sub < SUB; ++sub) {
-            uint4 fd[4], fa[4];
-            const char* tds = td + sub * PX1 * ROWB;
-            const char* tas = ta + sub * PX1 * ROWB;
-            if constexpr (sizeof(T) == 2) {
-                const int row = fg * 4 + (fi >> 2), colb = (fi & 3) * 8;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const char* q = tds + row * ROWB + (wn * 64 + j * 16) * 2 + colb;
-                    const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)q);
-                    const s16x4 x1 =
-                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * ROWB));
-                    const uint2 a0 = __builtin_bit_cast(uint2, x0), a1 = __builtin_bit_cast(uint2, x1);
-                    fd[j] = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const char* q = tas + row * ROWB + (wc * 64 + i * 16) * 2 + colb;
-                    const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)q);
-                    const s16x4 x1 =
-                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * ROWB));
-                    const uint2 a0 = __builtin_bit_cast(uint2, x0), a1 = __builtin_bit_cast(uint2, x1);
-                    fa[i] = make_uint4(a0.x, a0.y, a1.x, a1.y);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const char* q = tds + (fg * 4) * ROWB + (wn * 64 + j * 16 + fi) * 4;
-                    float4 v;
-                    v.x = *reinterpret_cast<const float*>(q);
-                    v.y = *reinterpret_cast<const float*>(q + ROWB);
-                    v.z = *reinterpret_cast<const float*>(q + 2 * ROWB);
-                    v.w = *reinterpret_cast<const float*>(q + 3 * ROWB);
-                    fd[j] = __builtin_bit_cast(uint4, v);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const char* q = tas + (fg * 4) * ROWB + (wc * 64 + i * 16 + fi) * 4;
-                    float4 v;
-                    v.x = *reinterpret_cast<const float*>(q);
-                    v.y = *reinterpret_cast<const float*>(q + ROWB);
-                    v.z = *reinterpret_cast<const float*>(q + 2 * ROWB);
-                    v.w = *reinterpret_cast<const float*>(q + 3 * ROWB);
-                    fa[i] = __builtin_bit_cast(uint4, v);
-                }
+            for (int j = 0; j < 4; ++j) {
+                const char* q = td + row * ROWB + (wn * 64 + j * 16) * 2 + colb;
+                const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)q);
+                const s16x4 x1 =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * ROWB));
+                const uint2 a0 = __builtin_bit_cast(uint2, x0), a1 = __builtin_bit_cast(uint2, x1);
+                fd[j] = make_uint4(a0.x, a0.y, a1.x, a1.y);
             }
-            // D[i][j] of mma16: i = row of the first operand (4 per lane), j = row of the second (lane & 15): the lane's
-            // column index runs along the contiguous dim of dw
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 4; ++i) {
+                const char* q = ta + row * ROWB + (wc * 64 + i * 16) * 2 + colb;
+                const s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)q);
+                const s16x4 x1 =
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 16 * ROWB));
+                const uint2 a0 = __builtin_bit_cast(uint2, x0), a1 = __builtin_bit_cast(uint2, x1);
+                fa[i] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            }
+        } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mma16<T>(fd[j], fa[i], acc[j][i]);
+            for (int j = 0; j < 4; ++j) {
+                const char* q = td + (fg * 4) * ROWB + (wn * 64 + j * 16 + fi) * 4;
+                float4 v;
+                v.x = *reinterpret_cast<const float*>(q);
+                v.y = *reinterpret_cast<const float*>(q + ROWB);
+                v.z = *reinterpret_cast<const float*>(q + 2 * ROWB);
+                v.w = *reinterpret_cast<const float*>(q + 3 * ROWB);
+                fd[j] = __builtin_bit_cast(uint4, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const char* q = ta + (fg * 4) * ROWB + (wc * 64 + i * 16 + fi) * 4;
+                float4 v;
+                v.x = *reinterpret_cast<const float*>(q);
+                v.y = *reinterpret_cast<const float*>(q + ROWB);
+                v.z = *reinterpret_cast<const float*>(q + 2 * ROWB);
+                v.w = *reinterpret_cast<const float*>(q + 3 * ROWB);
+                fa[i] = __builtin_bit_cast(uint4, v);
+            }
         }
+        // D[i][j] of mma16: i = row of the first operand (4 per lane), j = row of the second (lane & 15): the lane's
+        // column index runs along the contiguous dim of dw
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mma16<T>(fd[j], fa[i], acc[j][i]);
         if (more) store_step((s + 1) & 1);
         __syncthreads();
     }
@@ -454,53 +447,29 @@ extern "C" int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream) 
     p.lin = (a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad_t == 0 && a->pad_l == 0 && !a->upsample &&
              a->OH == a->IH && a->OW == a->IW)
                 ? 1 : 0;
+    const int px = 4 * epc;
+    const int total_steps = (p.M + px - 1) / px;
     const int tilesN = (p.N + 127) / 128, tilesK = (p.K + 127) / 128;
-    const int tiles = tilesN * tilesK;
-    const int px1 = 4 * epc;
-    const int steps1 = (p.M + px1 - 1) / px1;
     int splitm = a->splitm;
-    auto slices_for = [&](int total_steps) {
+    if (splitm <= 0) {
         // one round of resident blocks (2 per CU, a little oversubscribed): every further slice only adds a pass of
         // float atomics over dw (~3 ps per element).  tools/bench_backward.py --sweep: within ~10 % of the best
         // slice count on the conv / linear shapes of the 512 x 512 forward
-        int sm = (640 + tiles / 2) / tiles;
+        const int tiles = tilesN * tilesK;
+        splitm = (640 + tiles / 2) / tiles;
         const int cap = total_steps / 2;
-        if (sm > cap) sm = cap;
-        return sm < 1 ? 1 : sm;
-    };
-    // two k-extents per staged step when a slice still runs >= 8 of them (env MADM_WGRAD_SUB=1 / 2 forces one form: A/B)
-    int sub = (steps1 / (splitm > 0 ? splitm : slices_for(steps1)) >= 16) ? 2 : 1;
-    if (const char* e = getenv("MADM_WGRAD_SUB")) { if (*e) sub = (atoi(e) == 2) ? 2 : 1; }
-    const int px = px1 * sub;
-    const int total_steps = (p.M + px - 1) / px;
-    if (splitm <= 0) splitm = slices_for(total_steps);
+        if (splitm > cap) splitm = cap;
+        if (splitm < 1) splitm = 1;
+    }
     if (splitm > total_steps) splitm = total_steps;
     MADM_REQUIRE(splitm <= 65535 && tilesK <= 65535, "conv2d_wgrad: grid too large");
     p.steps_per_slice = (total_steps + splitm - 1) / splitm;
     splitm = (total_steps + p.steps_per_slice - 1) / p.steps_per_slice;
     dim3 grid((unsigned)tilesN, (unsigned)tilesK, (unsigned)splitm);
     hipStream_t s = (hipStream_t)stream;
-    const size_t rowb = 128 * (size_t)esz + (esz == 2 ? 32 : 16);
-    const size_t lds = 4 * (size_t)px * rowb;
-#define MADM_WGRAD_LAUNCH(T, SUB)                                                                                   \
-    {                                                                                                               \
-        auto kern = conv2d_wgrad_kernel<T, SUB>;                                                                    \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-            if (e != hipSuccess) {                                                                                  \
-                madm_set_error("conv2d_wgrad: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));     \
-                return MADM_ERR_LAUNCH;                                                                             \
-            }                                                                                                       \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
-        kern<<<grid, 256, lds, s>>>(p);                                                                             \
-    }
-    if (a->dtype == MADM_BF16) { if (sub == 2) MADM_WGRAD_LAUNCH(bf16_t, 2) else MADM_WGRAD_LAUNCH(bf16_t, 1) }
-    else if (a->dtype == MADM_F16) { if (sub == 2) MADM_WGRAD_LAUNCH(f16_t, 2) else MADM_WGRAD_LAUNCH(f16_t, 1) }
-    else { if (sub == 2) MADM_WGRAD_LAUNCH(float, 2) else MADM_WGRAD_LAUNCH(float, 1) }
-#undef MADM_WGRAD_LAUNCH
+    if (a->dtype == MADM_BF16) conv2d_wgrad_kernel<bf16_t><<<grid, 256, 0, s>>>(p);
+    else if (a->dtype == MADM_F16) conv2d_wgrad_kernel<f16_t><<<grid, 256, 0, s>>>(p);
+    else conv2d_wgrad_kernel<float><<<grid, 256, 0, s>>>(p);
     return madm_check_launch("conv2d_wgrad_kernel");
 }
 
