@@ -119,6 +119,73 @@ def test_conv2d(cuda, dtype, case):
     assert e < TOL[dtype], f"{name}: max rel err {e:.3e} l2 {l2:.3e}"
 
 
+
+H16_CASES = [
+    # name, B, Cin(list), H, W, Cout, fuse_gn (None / act), relu epilogue, residual, stats
+    ("full", 2, [128], 32, 32, 128, None, False, True, True),
+    ("ragged_n192", 1, [64], 21, 37, 192, None, False, True, True),
+    ("concat", 2, [128, 64], 16, 32, 128, None, False, False, True),
+    ("relu_nores", 2, [64], 16, 16, 256, None, True, False, False),
+    ("gn_silu", 2, [128], 32, 16, 128, "silu", False, True, True),
+    ("gn_relu_ragged", 1, [64], 19, 23, 64, "relu", False, False, True),
+    ("gn_none_concat_straddle", 2, [1280, 640], 16, 16, 64, None, False, False, False),
+    ("gn_silu_concat_straddle", 2, [1280, 640], 16, 16, 64, "silu", False, True, True),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", H16_CASES, ids=[c[0] for c in H16_CASES])
+def test_conv3x3_h16(cuda, dtype, case):
+    """The 16 x 16-patch halo conv (tile code 12: the dominant kernel of the metric) forced on small maps: full and ragged
+    patches, N not a multiple of the block width, two sources, every epilogue option (bias, time row, residual, ReLU,
+    fused output statistics) on both store paths (16-bit: LDS-transposed 16-byte stores; f32: direct), and the fused
+    GroupNorm(+SiLU / ReLU) input pass incl. groups straddling the source boundary and the packed-f16 form."""
+    from madm_amd import ops, packing
+    from madm_amd._lib import lib
+    name, B, cins, H, W, Cout, fuse, relu, with_res, with_stats = case
+    kt = ops.k_tile(dtype)
+    Cin = sum(cins)
+    xs = [_q(_gen((B, c, H, W), 30 + i) * (1.0 + 0.5 * i) + 0.25 * i, dtype) for i, c in enumerate(cins)]
+    w = _q(_gen((Cout, Cin, 3, 3), 3) / math.sqrt(Cin * 9), dtype)
+    bias, rowvec = _gen((Cout,), 4), _gen((B, Cout), 5)
+    h = torch.cat(xs, 1)
+    gn = None
+    toks = [to_tokens(x, dtype) for x in xs]
+    if fuse is not None or name.startswith("gn_"):
+        gamma, beta = 1.0 + 0.2 * _gen((Cin,), 6), 0.3 * _gen((Cin,), 7)
+        h = F.group_norm(h, 32, gamma, beta, eps=1e-5)
+        h = F.silu(h) if fuse == "silu" else (F.relu(h) if fuse == "relu" else h)
+        sts = []
+        for t in toks:
+            st = torch.zeros((B, t.shape[1], 2), dtype=torch.float64, device="cuda")
+            ops.groupnorm_stats(t, B, H * W, st)
+            sts.append(st)
+        gn = (sts, gamma.cuda(), beta.cuda(), 32, 1e-5, fuse if fuse is not None else False)
+    ref = F.conv2d(h, w, None, padding=1) + bias[None, :, None, None] + rowvec[:, :, None, None]
+    res = _q(_gen((B, Cout, H, W), 8), dtype) if with_res else None
+    if res is not None:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    wp = packing.pack_conv_weight(w, dtype, kt, splits=cins).cuda()
+    st_out = torch.zeros((B, Cout, 2), device="cuda", dtype=torch.float64) if with_stats else None
+    lib.madm_debug_set_conv_tile(12)
+    try:
+        out = ops.conv2d(toks[0], wp, B, H, W, N=Cout, x2=toks[1] if len(toks) > 1 else None, KH=3, KW=3, pad_t=1, pad_l=1,
+                         bias=bias.cuda(), rowvec=rowvec.cuda(), residual=None if res is None else to_tokens(res, dtype),
+                         epilogue=ops.EPI_RELU if relu else ops.EPI_NONE, stats=st_out, gn=gn, splitk=1)
+        torch.cuda.synchronize()
+    finally:
+        lib.madm_debug_set_conv_tile(0)
+    tol = {torch.float32: 3e-5, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]
+    e, l2 = rel_err(from_tokens(out, B, H, W), ref)
+    assert e < tol, f"{name}: max rel err {e:.3e} l2 {l2:.3e}"
+    if st_out is not None:
+        sums = st_out.float().cpu()
+        stol = {torch.float32: 1e-4, torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype]
+        assert rel_err(sums[..., 0], ref.sum((2, 3)))[0] < stol
+        assert rel_err(sums[..., 1], (ref ** 2).sum((2, 3)))[0] < stol
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_linear_geglu(cuda, dtype):
     from madm_amd import ops, packing
