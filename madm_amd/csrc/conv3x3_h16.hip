@@ -128,9 +128,11 @@ __device__ __forceinline__ void h16_epilogue(const IgemmP& p, f32x4 (&acc)[MI][B
 // registers as above) are rounded to T, written to an LDS tile [256 pixels][BN channels] (rows padded by 16 B) and leave as
 // 16-byte stores, 16 lanes per pixel row = full 256-byte lines -- the direct path stores 8-byte pieces of 16 different rows
 // per instruction and spent ~25 k clocks per block (in-kernel stamps), a quarter of a K = 1152 layer's block time.
+typedef __attribute__((address_space(3))) char h16_lds_char;
+
 template <typename T, int BN, int MI>
 __device__ __forceinline__ void h16_epilogue_lds(const IgemmP& p, f32x4 (&acc)[MI][BN / 32], int b, int py0, int px0, int n0,
-                                                 char* lds) {
+                                                 char* lds, h16_lds_char* lds3) {
     constexpr int NI = BN / 32;
     constexpr int ROW = BN * (int)sizeof(T) + 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,29 +156,40 @@ __device__ __forceinline__ void h16_epilogue_lds(const IgemmP& p, f32x4 (&acc)[M
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] += add[j];
     if (p.residual) {
-        const T* rbase = reinterpret_cast<const T*>(p.residual) + nb;
-        if (full) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // The residual tile [256 pixels][BN channels] comes in by LDS-DMA (full 256-byte lines, 64 one-KiB pieces = 4 pixel
+        // rows each, 16 per wave) and the lanes pick their 8-byte pieces out of the LDS: as 32 eight-byte global gathers per
+        // lane it cost 13 k clocks per block (stamps; the gathers of one wave cover 16 KB against a 32 KB L1).  The 16-byte
+        // chunk c of pixel row px lands at position c ^ (px & 15) (source-side swizzle, like the halo): the 16 pixel columns
+        // a read instruction covers hit 16 different positions.
+        static_assert(BN * sizeof(T) == 256, "residual DMA: one pixel row = 16 chunks");
+        const size_t rbytes = (size_t)p.M * (size_t)p.ldr * sizeof(T);
+        const __amdgpu_buffer_rsrc_t rsr =
+            __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (unsigned)(rbytes < 0xffffffffull ? rbytes : 0xffffffffull),
+                                              0x00020000);
+        const int pl = lane >> 4, pos = lane & 15;                 // pixel of the piece, LDS chunk position
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const T* rp = rbase + (size_t)((b * p.OH + py0 + wm * MI + i) * p.OW + px0 + frow) * p.ldr;
-                f32x4 r[NI];
+        for (int t = 0; t < 16; ++t) {
+            const int oy = py0 + wave * 4 + (t >> 2), ox = px0 + 4 * (t & 3) + pl;
+            const int c = pos ^ ((4 * (t & 3) + pl) & 15);        // global chunk that belongs at this position
+            const int n = n0 + c * (16 / (int)sizeof(T));
+            unsigned off = (unsigned)((((size_t)(b * p.OH + oy) * p.OW + ox) * p.ldr + n) * sizeof(T));
+            if (!full && (oy >= p.OH || ox >= p.OW || n >= p.N)) off = 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsr, lds3 + (wave * 16 + t) * 1024, 16, off, 0, 0, 0);
+        }
+        h16_wait_vmcnt<0>();
+        __syncthreads();
 #pragma unroll
-                for (int j = 0; j < NI; ++j) r[j] = load4<T>(rp + 16 * j);
+        for (int i = 0; i < MI; ++i) {
+            const int px = (wm * MI + i) * 16 + frow;
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] += r[j];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int oy = py0 + wm * MI + i, ox = px0 + frow;
-                if (oy < p.OH && ox < p.OW) {
-                    const T* rp = rbase + (size_t)((b * p.OH + oy) * p.OW + ox) * p.ldr;
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        if (nb + 16 * j < p.N) acc[i][j] += load4<T>(rp + 16 * j);
-                }
+            for (int j = 0; j < NI; ++j) {
+                const int c = wn * 8 + j * 2 + (fg >> 1);
+                acc[i][j] += load4<T>(reinterpret_cast<const T*>(lds + px * 256 + ((c ^ frow) * 16) + (fg & 1) * 8));
             }
         }
+        __syncthreads();   // the tile region is rewritten with the outputs below
+#endif
     }
     if (p.epilogue == MADM_EPI_RELU) {
 #pragma unroll
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, int
     h16_wait_vmcnt<0>();
     __syncthreads();   // the LDS becomes the statistics scratch of the epilogue
     // WIDE (chosen by the launcher): 16-bit outputs without split-K / GEGLU whose rows keep 16-byte alignment
-    if constexpr (WIDE) h16_epilogue_lds<T, BN, MI>(p, acc, b, py0, px0, n0, smem_raw);
+    if constexpr (WIDE) h16_epilogue_lds<T, BN, MI>(p, acc, b, py0, px0, n0, smem_raw, lds0);
     else h16_epilogue<T, BN, MI>(p, acc, b, py0, px0, n0, z, reinterpret_cast<float*>(smem_raw));
     H16_STAMP(5);
 #endif
