@@ -189,7 +189,7 @@ def run_train(args, rank, world, device, dist, mdist):
                "allreduce_started_during_backward_frac": trainer.last_overlap_frac,
                "last_losses": losses, "grad_norm": norm, "stepped": stepped, "loss_scale": trainer.scale,
                "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -498,10 +498,28 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
                               for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         if world == 1 and not args.no_cpu_baseline and args.workload == "extract":
             out["cpu_baseline"] = cpu_baseline(args.size)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
 
+_RESULT_FD = None
+
+
+def emit(out):
+    """The ONE JSON line of the contract, on the process's real stdout."""
+    line = (json.dumps(out) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
 if __name__ == "__main__":
+    # everything else that writes to file descriptor 1 (the RCCL version banner at process-group start / teardown, library
+    # chatter) goes to stderr: rank 0's stdout carries exactly one line
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     main()

@@ -17,9 +17,10 @@ def init(backend=None, device=None):
     """Initialises the default process group from the torchrun environment (no-op for world size 1)."""
     import torch.distributed as dist
     rank, local_rank, world = env_world()
-    if world == 1:
+    if world == 1 and not os.environ.get("MADM_FORCE_PROCESS_GROUP"):   # (the switch: the N > 1 code path on one GPU)
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {}
