@@ -5,6 +5,7 @@ pointers of CUDA(HIP) tensors to libmadm_hip.so on the current stream.  Activati
 channels-last 2-D tensors ``[B*H*W, C]``.  There is no fallback path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -52,6 +53,8 @@ _TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64", 4: "conv
                10: "conv3x3_halo_dma_x64", 11: "igemm_glds_64x64s", 12: "conv3x3_h16_x128"}
 EXP_NO_STATS = bool(int(__import__('os').environ.get('MADM_EXP_NO_STATS', '0')))   # timing experiment only
 FORCE_SPLITK = None   # tools/tune_insitu.py: split-K factor forced on every small-M launch
+if os.environ.get("MADM_EXP_SPLITK"):   # experiment: e.g. 1 = no split-K anywhere (does the staged pipeline still want it?)
+    FORCE_SPLITK = int(os.environ["MADM_EXP_SPLITK"])
 FUSE_GN = True   # fold GroupNorm(+SiLU) into eligible 3x3 convs (debug switch)
 HALO_MIN_W = int(__import__("os").environ.get("MADM_HALO_MIN_W", "8"))   # mirrors halo_min_width() of igemm.hip
 import os as _os
