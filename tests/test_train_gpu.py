@@ -319,3 +319,62 @@ def test_color_augmentation_kernels(cuda):
     p.update(color_jitter=0.9, blur=0.9)
     out = augment.strong_color(p, data.cuda(), generator=torch.Generator().manual_seed(1), rng=np.random.RandomState(2))
     assert out.shape == data.shape and not torch.equal(out.cpu(), data) and 0 <= out.min() and out.max() <= 1
+
+
+def test_table_adamw_matches_torch_adamw_with_groups(cuda):
+    """optim.default_optimizer_params + optim.TableAdamW against torch.optim.AdamW over the parameter groups
+    get_default_optimizer_params_unet builds (utils/parameter_count.py:120-215): weight decay > 0 on weights, none on
+    normalisation modules and on parameters named 'bias', a separate lr under a module path containing 'unet', gradient
+    clipping, a loss scale, and a parameter WITHOUT a gradient in one step (torch skips it: no decay, no moment update,
+    its step count does not advance)."""
+    import copy
+    from madm_amd import optim
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.unet = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.LayerNorm(40), torch.nn.Linear(40, 8, bias=False))
+            self.head = torch.nn.ModuleDict({"conv": torch.nn.Conv2d(8, 16, 3), "gn": torch.nn.GroupNorm(4, 16),
+                                             "bn": torch.nn.BatchNorm2d(16)})
+            self.alpha = torch.nn.Parameter(torch.randn(5))
+
+    torch.manual_seed(3)
+    net = Net().cuda()
+    ref = copy.deepcopy(net)
+    lr, unet_lr, wd, clip, scale = 3e-3, 7e-4, 0.05, 0.7, 128.0
+    table = optim.default_optimizer_params(net, lr, wd, weight_decay_norm=0.0, weight_decay_bias=0.0, unet_lr=unet_lr)
+    got = {id(p): (l, w) for p, l, w in table}
+    names = dict(net.named_parameters())
+    assert got[id(names["unet.0.weight"])] == (unet_lr, wd) and got[id(names["unet.0.bias"])] == (unet_lr, 0.0)
+    assert got[id(names["unet.1.weight"])] == (unet_lr, 0.0) and got[id(names["head.conv.weight"])] == (lr, wd)
+    assert got[id(names["head.gn.weight"])] == (lr, 0.0) and got[id(names["head.bn.bias"])] == (lr, 0.0)
+    assert got[id(names["alpha"])] == (lr, wd)
+    opt = optim.TableAdamW(table, betas=(0.9, 0.999), eps=1e-8)
+    rnames = dict(ref.named_parameters())
+    groups = []
+    for n, p in rnames.items():
+        is_norm = any(k in n for k in ("unet.1.", "head.gn.", "head.bn."))
+        groups.append({"params": [p], "lr": unet_lr if n.startswith("unet") else lr,
+                       "weight_decay": 0.0 if (is_norm or n.endswith("bias")) else wd})
+    ropt = torch.optim.AdamW(groups, betas=(0.9, 0.999), eps=1e-8)
+    params = dict(net.named_parameters())      # views into the flat buffer now
+    gen = torch.Generator().manual_seed(11)
+    for step in range(4):
+        opt.zero_grad()
+        ropt.zero_grad(set_to_none=True)
+        skip = "head.conv.weight" if step == 1 else None
+        touched = set()
+        for n, p in params.items():
+            if n == skip:
+                continue
+            g = torch.randn(p.shape, generator=gen).cuda()
+            p.grad.copy_(g * scale)
+            rnames[n].grad = g.clone()
+            touched.add(id(p))
+        torch.nn.utils.clip_grad_norm_([q for q in ref.parameters() if q.grad is not None], clip)
+        ropt.step()
+        norm, stepped = opt.step(clip_grad=clip, loss_scale=scale, touched=touched)
+        assert stepped and norm > 0
+        for n, p in params.items():
+            e = (p.detach() - rnames[n].detach()).abs().max().item()
+            assert e < 2e-6, f"step {step} {n}: {e:.2e}"
