@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, int
                                                                          p.in2 ? p.bytes2 : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.bytesw, 0x00020000);
 
+    const int ush = __builtin_amdgcn_readfirstlane(p.upsample ? 1 : 0);   // (never together with FUSE: the launcher checks)
     const int nchunks = p.Ctot / BKE;
     const int ck0 = (nchunks * z) / p.splitk;
     const int ck1 = (nchunks * (z + 1)) / p.splitk;
@@ -337,9 +338,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, int
                 const int h_ = (wave + 4 * i) * 8 + hlv_;                                               \
                 const int hy_ = h_ / H16_W, hx_ = h_ - hy_ * H16_W;                                     \
                 const int iy_ = py0 - 1 + hy_, ix_ = px0 - 1 + hx_;                                     \
-                const bool ok_ = h_ < H16_PIX && (unsigned)iy_ < (unsigned)p.IH && (unsigned)ix_ < (unsigned)p.IW; \
-                const unsigned off_ = (unsigned)(((b * p.IH + iy_) * p.IW + ix_) * ld_ + cofs_ + (cl ^ (hx_ & 7)) * EPC) * \
-                                      (unsigned)sizeof(T);                                              \
+                /* nearest-2x upsample folded into the gather (ush = 1): halo pixel (iy, ix) of the upsampled map reads    */ \
+                /* source pixel (iy >> 1, ix >> 1); the zero padding lies outside the UPSAMPLED map                     */ \
+                const bool ok_ = h_ < H16_PIX && (unsigned)iy_ < (unsigned)(p.IH << ush) &&                 \
+                                 (unsigned)ix_ < (unsigned)(p.IW << ush);                                   \
+                const unsigned off_ = (unsigned)(((b * p.IH + (iy_ >> ush)) * p.IW + (ix_ >> ush)) * ld_ + cofs_ + \
+                                                 (cl ^ (hx_ & 7)) * EPC) * (unsigned)sizeof(T);             \
                 lds_char* dst_ = lds0 + (wave + 4 * i) * 1024;                                          \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, dst_, 16, ok_ ? off_ : OOB, 0, 0, 0);     \
             }                                                                                           \
@@ -580,6 +584,10 @@ int launch_h16_one(const IgemmP& p0, hipStream_t s) {
 template <typename T>
 int launch_conv3x3_h16(const IgemmP& p, int bn, hipStream_t s) {
     const bool fuse = p.gn_sums1 != nullptr;
+    if (fuse && p.upsample) {
+        madm_set_error("conv3x3 (16 x 16 patches): GroupNorm fusion and the upsample gather do not combine");
+        return MADM_ERR_UNSUPPORTED;
+    }
     (void)bn;
     if constexpr (sizeof(T) == 2) {
         if (p.splitk == 1 && !p.out_f32 && p.epilogue != MADM_EPI_GEGLU && (p.ldo & 7) == 0 && (p.N & 7) == 0)

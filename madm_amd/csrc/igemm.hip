@@ -629,7 +629,16 @@ bool h16_pays(const madm_conv2d_args* a) {
     return blocks >= 384;
 }
 
+// nearest-2x upsample + 3x3 conv (Upsample2D of the VAE decoder / UNet): only the 16 x 16-patch kernel folds the
+// upsample into its halo gather (igemm 128x64 on the 256-channel 512 x 512 layer: 456 us, this kernel: see DESIGN.md)
+bool h16_upsample_eligible(const madm_conv2d_args* a) {
+    return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad_t == 1 && a->pad_l == 1 && a->upsample &&
+           a->OH == 2 * a->IH && a->OW == 2 * a->IW && !a->gn_sums1 && a->epilogue != MADM_EPI_GEGLU && a->OH >= 16 &&
+           a->OW >= 16;
+}
+
 int pick_tile(const madm_conv2d_args* a) {
+    if (h16_upsample_eligible(a) && (g_tile_override == 12 || (g_tile_override == 0 && h16_pays(a)))) return 12;
     const int t = pick_tile_raw(a);
     if (t == 12 && (a->OH < 16 || a->OW < 16)) return 9;   // the 16 x 16-patch kernel needs a map of at least one patch
     if ((t == 4 || t == 9) && g_tile_override == 0 && h16_pays(a)) return 12;

@@ -71,6 +71,9 @@ CONV_CASES = [
     ("halodma_concat", 2, [128, 64], 8, 16, 128, 3, 1, "same", False, 10, 1),
     ("halodma_splitk", 2, [256], 8, 16, 64, 3, 1, "same", False, 10, 2),
     ("halodma_longk", 2, [640], 8, 16, 128, 3, 1, "same", False, 9, 1),
+    # 12 = 16 x 16-patch halo conv with the nearest-2x upsample folded into its halo gather (Upsample2D), full / ragged
+    ("h16_upsample", 2, [64], 16, 16, 128, 3, 1, "same", True, 12, 1),
+    ("h16_upsample_ragged_concat", 1, [128, 64], 9, 13, 192, 3, 1, "same", True, 12, 1),
 ]
 
 
