@@ -328,7 +328,8 @@ int madm_argmax_nchw_f32(const float* x, int64_t* out, int B, int K, size_t HW, 
  * is ACCUMULATED into (gradient accumulation; zero it for a plain gradient); the pixel range is split over `splitm`
  * grid slices (0 = choose) that add their partial tiles with float atomics, so the low-order bits depend on
  * scheduling, like torch's own non-deterministic wgrad algorithms.
- * bias gradient = column sums of dout: madm_colsum.
+ * bias gradient = column sums of dout: madm_colsum, or ``dbias`` below (the blocks of the first weight-column tile add up
+ * the dout rows they stream anyway: no second pass over dout, no second launch).
  *
  * Data gradient of a stride-1 layer (3x3 / pad 1, 1x1, linear): din = madm_conv2d_fwd(dout, wt) with
  * pad' = KH - 1 - pad and wt[c][taps - 1 - t][n] = w[n][t][c], produced by madm_pack_dgrad_weights
@@ -346,6 +347,7 @@ typedef struct {
     int B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
     int N;                /* multiple of 4 */
     int splitm;           /* pixel slices; 0 = choose for the MI355X grid */
+    float* dbias;         /* NULL or f32 [N], accumulated into: sum over the M rows of dout (nn.Conv2d / nn.Linear bias.grad) */
 } madm_conv2d_wgrad_args;
 int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream);
 int madm_pack_dgrad_weights(int dtype, const void* w, void* wt, int N, int taps, int C, void* stream);

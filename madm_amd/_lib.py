@@ -69,6 +69,7 @@ class Conv2dWgradArgs(ctypes.Structure):
         ("KH", c_int), ("KW", c_int), ("stride", c_int), ("pad_t", c_int), ("pad_l", c_int), ("upsample", c_int),
         ("N", c_int),
         ("splitm", c_int),
+        ("dbias", c_void_p),
     ]
 
 

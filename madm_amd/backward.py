@@ -46,12 +46,13 @@ def conv2d_backward(conv, x, dout, x2=None, need_dx=True, dres=None, upsample=Fa
         dout = torch.nn.functional.pad(dout, (0, packing.round_up(dout.shape[1], kt) - dout.shape[1]))   # count fills a K-tile
     grads = {}
     if need_dw:   # False: frozen layer (the reference's LoRA mode), only the data gradient flows
+        db = ops.zeros_f32((dout.shape[1],), dout.device) if conv.bias is not None else None   # gathered by the same launch
         dwp = ops.conv2d_wgrad(x.t, dout, x.B, x.H, x.W, x2=None if x2 is None else x2.t, KH=k, KW=k,
-                               stride=conv.stride, pad_t=pad, pad_l=pad, OH=OH, OW=OW, upsample=upsample)
+                               stride=conv.stride, pad_t=pad, pad_l=pad, OH=OH, OW=OW, upsample=upsample, dbias=db)
         grads["weight"] = packing.unpack_conv_weight_grad(dwp[:conv.out_channels], conv.in_channels, k, k, kt,
                                                           splits=splits)
         if conv.bias is not None:
-            grads["bias"] = ops.colsum(dout, 1, x.B * OH * OW)[0, :conv.out_channels]
+            grads["bias"] = db[:conv.out_channels]
     dx = None
     if need_dx:
         def build_wt():
@@ -84,10 +85,11 @@ def linear_backward(lin, x, dout, need_dx=True, need_dw=True):
     M = x.shape[0]
     grads = {}
     if need_dw:
-        dwp = ops.conv2d_wgrad(x, dout, 1, M, 1)
+        db = ops.zeros_f32((dout.shape[1],), dout.device) if lin.bias is not None else None
+        dwp = ops.conv2d_wgrad(x, dout, 1, M, 1, dbias=db)
         grads["weight"] = dwp[:, :lin.in_features].contiguous()
         if lin.bias is not None:
-            grads["bias"] = _colsum_per_image(dout, 1, M)[0]
+            grads["bias"] = db
     dx = None
     if need_dx:
         wt = lin._cache_get((dtype, "dgrad"), lambda: ops.pack_dgrad_weights(lin.packed(dtype)[0], 1))
@@ -173,8 +175,8 @@ def fused_proj_backward(fp, names, x, dout, need_dx=True, base_grads=True):
         n_off.append(n_off[-1] + b_.out_features)
     grads = {}
     if base_grads:
-        dW = ops.conv2d_wgrad(x, dout, 1, M, 1)
-        colsum = _colsum_per_image(dout, 1, M)[0] if bias is not None else None
+        colsum = ops.zeros_f32((dout.shape[1],), dout.device) if bias is not None else None
+        dW = ops.conv2d_wgrad(x, dout, 1, M, 1, dbias=colsum)
         for i, (l, nm) in enumerate(zip(layers, names)):
             pre = _layer_names(l, nm)
             grads[pre + ".weight"] = dW[n_off[i]:n_off[i + 1], :K].contiguous()
@@ -264,8 +266,8 @@ def feed_forward_backward(ff, x, dout, base_grads=True):
     pre = ops.linear(x, w, bias=b)                                        # [M, 8C] interleaved (value, gate)
     dpre = ops.geglu_backward(pre, dg.contiguous())
     if base_grads:
-        dwi = ops.conv2d_wgrad(x, dpre, 1, M, 1)[:, :geglu.proj.in_features]
-        dbi = _colsum_per_image(dpre, 1, M)[0]
+        dbi = ops.zeros_f32((dpre.shape[1],), dpre.device)
+        dwi = ops.conv2d_wgrad(x, dpre, 1, M, 1, dbias=dbi)[:, :geglu.proj.in_features]
         half = dwi.shape[0] // 2
         # rows are interleaved (value_j, gate_j): back to diffusers' (value | gate) chunk order
         grads["net.0.proj.weight"] = torch.cat([dwi[0::2], dwi[1::2]], 0).contiguous()

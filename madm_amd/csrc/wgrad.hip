@@ -24,6 +24,7 @@ struct WgradP {
     const char* in1; const char* in2; const char* dout; float* dw;
     int C1, C2, Ctot, ld1, ld2, ldd, B, IH, IW, OH, OW, KH, KW, stride, pad_t, pad_l, upsample;
     int N, K, M, steps_per_slice, lin;
+    float* dbias;
     unsigned bytes1, bytes2, bytesd;
 };
 
@@ -107,6 +108,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
             }
         }
     };
+    // bias gradient: the blocks of the first weight-column tile add up the dout chunks they stage (rows beyond M arrive
+    // as zeros); reduced over the block's row slots at the end
+    const bool do_bias = p.dbias != nullptr && blockIdx.y == 0;
+    float bsum[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) bsum[j] = 0.f;
     auto store_step = [&](int stage) {
         char* d = smem + stage * 2 * TILEB;
 #pragma unroll
@@ -114,6 +121,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
             const int off = (r0 + RPP * i) * ROWB + cc * 16;
             *reinterpret_cast<u32x4*>(d + off) = rd[i];
             *reinterpret_cast<u32x4*>(d + TILEB + off) = ra[i];
+            if (do_bias) {
+                float f[EPC];
+                chunk_to_f32<T>(__builtin_bit_cast(uint4, rd[i]), f);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) bsum[j] += f[j];
+            }
         }
     };
 
@@ -182,6 +195,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
             for (int i = 0; i < 4; ++i) mma16<T>(fd[j], fa[i], acc[j][i]);
         if (more) store_step((s + 1) & 1);
         __syncthreads();
+    }
+
+    if (do_bias) {   // (the loop's last barrier has passed: the staging LDS is free)
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) red[r0 * 128 + cc * EPC + j] = bsum[j];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N) {
+            float t = 0.f;
+            for (int r = 0; r < RPP; ++r) t += red[r * 128 + tid];
+            unsafeAtomicAdd(p.dbias + n0 + tid, t);
+        }
     }
 
     // lane holds dw[n = nb + 4 fg + r][k = kb + fi]: one instruction covers 4 rows x 64 contiguous bytes.  A single
@@ -434,6 +459,7 @@ extern "C" int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream) 
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW; p.KH = a->KH; p.KW = a->KW;
     p.stride = a->stride; p.pad_t = a->pad_t; p.pad_l = a->pad_l; p.upsample = a->upsample ? 1 : 0;
     p.N = a->N; p.K = a->KH * a->KW * p.Ctot;
+    p.dbias = a->dbias;
     const long long M = (long long)a->B * a->OH * a->OW;
     const long long in_rows = (long long)a->B * a->IH * a->IW;
     MADM_REQUIRE(M < (1ll << 30) && in_rows * p.ld1 * (long long)esz < (1ll << 31) &&

@@ -341,9 +341,10 @@ class DAFormerHead(nn.Module):
         grads = {}
         # ---- conv_seg ----
         N = dlogits.shape[1]
-        dwp = ops.conv2d_wgrad(hd, dlogits, B, H, W)                                  # [N, C]
+        db = ops.zeros_f32((N,), dlogits.device)
+        dwp = ops.conv2d_wgrad(hd, dlogits, B, H, W, dbias=db)                        # [N, C]; bias sums by the same launch
         grads["conv_seg.weight"] = dwp[:K, :C].reshape(K, C, 1, 1).contiguous()
-        grads["conv_seg.bias"] = ops.colsum(dlogits, 1, dlogits.shape[0])[0, :K].contiguous()
+        grads["conv_seg.bias"] = db[:K].contiguous()
         wt = self._cls_dgrad_weights(dtype, N)
         dhd = ops.conv2d_dgrad(dlogits, wt, B, H, W, C=wt.shape[0])
         dh = dhd if scale is None else ops.scale_channels(dhd, scale, B, H * W)

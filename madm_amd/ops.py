@@ -216,10 +216,11 @@ def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=No
 
 
 def conv2d_wgrad(x1, dout, B, IH, IW, *, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
-                 upsample=False, dw=None, splitm=0):
+                 upsample=False, dw=None, splitm=0, dbias=None):
     """Weight gradient of :func:`conv2d` (torch autograd in the reference, engine/train_loop.py:203-217):
     dw[n][(kh, kw, c)] += sum_m dout[m][n] * A(m, k).  x1 / x2: the tensors the forward conv read; dout: [B*OH*OW, N];
-    dw: f32 [N, KH*KW*(C1+C2)], ACCUMULATED into (a zeroed one is created when None)."""
+    dw: f32 [N, KH*KW*(C1+C2)], ACCUMULATED into (a zeroed one is created when None); dbias: None or f32 [N], accumulated
+    into: the column sums of dout (the bias gradient), gathered by the same launch."""
     _need_cuda(x1, x2, dout, dw)
     C1 = x1.shape[1]
     C2 = 0 if x2 is None else x2.shape[1]
@@ -248,6 +249,10 @@ def conv2d_wgrad(x1, dout, B, IH, IW, *, x2=None, KH=1, KW=1, stride=1, pad_t=0,
     a.upsample = 1 if upsample else 0
     a.N = N
     a.splitm = int(splitm)
+    if dbias is not None:
+        _need_cuda(dbias)
+        assert dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == N
+        a.dbias = dbias.data_ptr()
     if PROFILE is None:
         check(lib.madm_conv2d_wgrad(ctypes.byref(a), _stream()), "madm_conv2d_wgrad")
     else:

@@ -366,9 +366,13 @@ def test_conv2d_wgrad(cuda, dtype, case):
 
     cpads = [packing.round_up(c, kt) for c in cins]
     toks = [to_tokens(xi, dtype, cp) for xi, cp in zip(xs, cpads)]
+    db = torch.zeros(dy.shape[1], device="cuda")
     dw = ops.conv2d_wgrad(toks[0], to_tokens(dy, dtype), B, H, W, x2=toks[1] if len(toks) > 1 else None, KH=KH, KW=KH,
-                          stride=stride, pad_t=pad_t, pad_l=pad_l, OH=OH, OW=OW, upsample=ups, splitm=splitm)
+                          stride=stride, pad_t=pad_t, pad_l=pad_l, OH=OH, OW=OW, upsample=ups, splitm=splitm, dbias=db)
     torch.cuda.synchronize()
+    # the bias gradient gathered by the same launch: column sums of dout over all pixels
+    eb, _ = rel_err(db.cpu(), dy.sum((0, 2, 3)))
+    assert eb < 2e-5, f"{name}: bias gradient {eb:.3e}"
     got = packing.unpack_conv_weight_grad(dw.cpu(), Cin, KH, KH, kt, splits=cins)
     e, l2 = rel_err(got, ref)
     # same operands, f32 accumulation in both modes: only the summation order differs
