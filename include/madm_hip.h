@@ -234,6 +234,14 @@ int madm_image_to_nhwc(int dtype, const float* img, void* out, int B, int C, int
 int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H, int W, int Kpad,
                             float mean, float std, float* minmax, void* stream);
 
+/* The stem itself, without the detour: out[pixel][n] (dtype, row stride ldo) = bias[n] + sum_k wT[k][n] * x_k, x_k the
+ * normalised image value of tap k = (kh*3 + kw)*3 + c (zero outside the image), N = 128 (the SD VAE's conv_in), exact f32
+ * FMAs; wT f32 [27][N]; stats (NULL or f64 [B][N][2], zeroed by the caller) += per-(image, channel) sum / sum of squares
+ * of the output (the statistics of the GroupNorm that follows, as the conv epilogues produce them); minmax as above.
+ * Replaces vae.encoder.conv_in of vae_encoder (ldm_diffusers.py:287) together with the normalisation of :145-147. */
+int madm_stem_conv3x3(int dtype, const float* img, const float* wT, const float* bias, void* out, int ldo, int B, int H,
+                      int W, int N, float mean, float std, double* stats, float* minmax, void* stream);
+
 /* moments [B*HW][ldm] (dtype; channels 0..3 = posterior mean) ->
  *   latents_nchw[B,4,h,w] f32 = mean * scaling_factor                     (ldm_diffusers.py:303-308)
  *   noisy[B*HW][Cpad] dtype   = sqrt_ac[t_b] * latents + sqrt_1mac[t_b] * noise   (:349-360)

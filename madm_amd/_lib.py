@@ -119,6 +119,8 @@ SYMBOLS = [
     ("madm_attention_fwd", c_int, [ctypes.POINTER(AttentionArgs), c_void_p]),
     ("madm_image_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                                    c_float, c_void_p, c_void_p]),
+    ("madm_stem_conv3x3", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                  c_float, c_void_p, c_void_p, c_void_p]),
     ("madm_image_to_im2col3x3", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float,
                                         c_void_p, c_void_p]),
     ("madm_latents_add_noise", c_int, [c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,

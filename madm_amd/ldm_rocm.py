@@ -40,11 +40,19 @@ def _compute_dtype(m):
     return getattr(m, "compute_dtype", torch.bfloat16)
 
 
+class RawImage:
+    """The f32 NCHW image with its normalisation, handed to sd_vae.AutoencoderKL.encode_moments: the stem kernel
+    (madm_stem_conv3x3) normalises and convolves in one pass."""
+
+    def __init__(self, images, dtype, mean, std, minmax):
+        self.images, self.dtype, self.mean, self.std, self.minmax = images, dtype, mean, std, minmax
+        self.B, self.H, self.W = images.shape[0], images.shape[2], images.shape[3]
+
+
 def _img_tokens(images, dtype, mean=0.0, std=1.0, minmax=None):
-    """Normalised image as the im2col rows of the VAE stem conv (sd_vae.AutoencoderKL.encode_moments)."""
+    """The image as encode_moments takes it (normalised inside the stem kernel)."""
     assert images.shape[1] == 3, "the SD VAE encoder takes 3-channel images"
-    return Tok(ops.image_to_im2col3x3(images.float().contiguous(), dtype, ops.k_tile(dtype), mean, std, minmax),
-               images.shape[0], images.shape[2], images.shape[3])
+    return RawImage(images.float().contiguous(), dtype, mean, std, minmax)
 
 
 @torch.no_grad()

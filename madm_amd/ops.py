@@ -588,6 +588,22 @@ def image_to_nhwc(img, dtype, Cpad, mean, std, minmax=None):
     return out
 
 
+def stem_conv3x3(img, wT, bias, dtype, mean, std, stats=None, minmax=None):
+    """The SD VAE stem conv straight from the f32 NCHW image (madm_stem_conv3x3): [B,3,H,W] -> tokens [B*H*W, 128]."""
+    _need_cuda(img, wT, bias, stats, minmax)
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4 and img.shape[1] == 3
+    assert wT.dtype == torch.float32 and wT.is_contiguous() and wT.shape[0] == 27 and bias.dtype == torch.float32
+    B, _, H, W = img.shape
+    N = wT.shape[1]
+    out = torch.empty((B * H * W, N), dtype=dtype, device=img.device)
+    with _Prof("stem_conv3x3" + _SUFFIX[dtype], 2.0 * B * H * W * N * 27, f"B{B} {H}x{W} N{N}",
+               img.numel() * 4 + out.numel() * out.element_size()):
+        check(lib.madm_stem_conv3x3(dtype_code(dtype), img.data_ptr(), wT.data_ptr(), bias.data_ptr(), out.data_ptr(), N, B, H,
+                                    W, N, float(mean), float(std), _ptr(stats), _ptr(minmax), _stream()),
+              "madm_stem_conv3x3")
+    return out
+
+
 def image_to_im2col3x3(img, dtype, Kpad, mean, std, minmax=None):
     """[B,3,H,W] f32 -> im2col rows [B*H*W, Kpad] of the normalised image for a 3x3/pad-1 stem conv."""
     _need_cuda(img, minmax)

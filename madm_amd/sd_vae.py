@@ -154,22 +154,34 @@ class AutoencoderKL(_Packed):
 
     # ---- encoder: vae_encoder (ldm_diffusers.py:283-311) up to ``moments`` ----
     def encode_moments(self, x, encoder_block_indices=()):
-        """x: Tok of the normalised image as im2col rows of the 3x3 stem (ops.image_to_im2col3x3).  Returns
-        (moments Tok [.., 8] = quant_conv(encoder(x)), taps list[Tok]).  quant_conv (1x1, 8->8) is
-        folded into encoder.conv_out's weights: W' = Wq W, b' = Wq b + bq (exact composition)."""
+        """x: ldm_rocm.RawImage (f32 NCHW image + its normalisation: the stem kernel madm_stem_conv3x3 reads it directly), or
+        a Tok of the normalised image as im2col rows of the 3x3 stem (ops.image_to_im2col3x3; stems other than the SD
+        VAE's 3 -> 128).  Returns (moments Tok [.., 8] = quant_conv(encoder(x)), taps list[Tok]).  quant_conv (1x1, 8->8)
+        is folded into encoder.conv_out's weights: W' = Wq W, b' = Wq b + bq (exact composition)."""
         enc = self.encoder
         taps, index = [], 0
-        dtype = x.t.dtype
+        dtype = x.t.dtype if isinstance(x, Tok) else x.dtype
+        if not isinstance(x, Tok) and enc.conv_in.out_channels != 128:   # (not the SD VAE: the GEMM form of the stem)
+            x = Tok(ops.image_to_im2col3x3(x.images, x.dtype, ops.k_tile(x.dtype), x.mean, x.std, x.minmax), x.B, x.H, x.W)
+        if not isinstance(x, Tok):
+            def build_stem_direct():   # [128,3,3,3] -> f32 [k = (r*3+s)*3 + c][128]
+                w = enc.conv_in.weight.detach().float().permute(2, 3, 1, 0).reshape(27, enc.conv_in.out_channels)
+                return w.contiguous(), enc.conv_in.bias.detach().float().contiguous()
 
-        def build_stem():   # [128,3,3,3] -> [128][k = (r*3+s)*3 + c] padded to the K-tile
-            w = enc.conv_in.weight.detach().float().permute(0, 2, 3, 1).reshape(enc.conv_in.out_channels, 27)
-            return (packing.pack_linear_weight(w, dtype, ops.k_tile(dtype)),
-                    enc.conv_in.bias.detach().float().contiguous())
+            wT, bs = self._cache_get(("stem_direct",), build_stem_direct)
+            st = ops.new_chsums(x.B, wT.shape[1], x.images.device)
+            h = Tok(ops.stem_conv3x3(x.images, wT, bs, x.dtype, x.mean, x.std, stats=st, minmax=x.minmax),
+                    x.B, x.H, x.W, st)
+        else:
+            def build_stem():   # [128,3,3,3] -> [128][k = (r*3+s)*3 + c] padded to the K-tile
+                w = enc.conv_in.weight.detach().float().permute(0, 2, 3, 1).reshape(enc.conv_in.out_channels, 27)
+                return (packing.pack_linear_weight(w, dtype, ops.k_tile(dtype)),
+                        enc.conv_in.bias.detach().float().contiguous())
 
-        ws, bs = self._cache_get((dtype, "stem"), build_stem)
-        st = ops.new_chsums(x.B, ws.shape[0], x.t.device)
-        h = Tok(ops.linear(x.t, ws, bias=bs, alg_nk=(enc.conv_in.out_channels, 27), stats=st, B=x.B),
-                x.B, x.H, x.W, st)
+            ws, bs = self._cache_get((dtype, "stem"), build_stem)
+            st = ops.new_chsums(x.B, ws.shape[0], x.t.device)
+            h = Tok(ops.linear(x.t, ws, bias=bs, alg_nk=(enc.conv_in.out_channels, 27), stats=st, B=x.B),
+                    x.B, x.H, x.W, st)
         for blk in enc.down_blocks:
             for resnet in blk.resnets:
                 h = resnet(h)

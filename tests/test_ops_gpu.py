@@ -189,6 +189,32 @@ def test_conv3x3_h16(cuda, dtype, case):
         assert rel_err(sums[..., 0], ref.sum((2, 3)))[0] < stol
         assert rel_err(sums[..., 1], (ref ** 2).sum((2, 3)))[0] < stol
 
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape", [(2, 16, 128), (1, 37, 133), (3, 5, 300)], ids=["full_seg", "ragged", "multi_seg"])
+def test_stem_conv3x3(cuda, dtype, shape):
+    """madm_stem_conv3x3: normalise + the VAE stem conv (3 -> 128, 3x3 / pad 1, zero padding AFTER the normalisation) +
+    bias + fused output statistics + range probe, straight from the f32 NCHW image."""
+    from madm_amd import ops
+    B, H, W = shape
+    img = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(5))
+    w = _gen((128, 3, 3, 3), 6) / math.sqrt(27)
+    bias = _gen((128,), 7)
+    mean, std = 0.5, 0.5
+    ref = F.conv2d((img - mean) / std, w, bias, padding=1)
+    wT = w.permute(2, 3, 1, 0).reshape(27, 128).contiguous().cuda()
+    st = torch.zeros((B, 128, 2), dtype=torch.float64, device="cuda")
+    mm = torch.tensor([float("inf"), float("-inf")], device="cuda")
+    out = ops.stem_conv3x3(img.cuda(), wT, bias.cuda(), dtype, mean, std, stats=st, minmax=mm)
+    torch.cuda.synchronize()
+    e, l2 = rel_err(from_tokens(out, B, H, W), ref)
+    assert e < {torch.float32: 2e-6, torch.bfloat16: 6e-3, torch.float16: 8e-4}[dtype], f"{e:.3e} {l2:.3e}"
+    sums = st.float().cpu()
+    assert rel_err(sums[..., 0], ref.sum((2, 3)))[0] < 1e-4 and rel_err(sums[..., 1], (ref ** 2).sum((2, 3)))[0] < 1e-4
+    lo, hi = mm.tolist()
+    x = (img - mean) / std
+    assert abs(lo - float(x.min())) < 1e-6 and abs(hi - float(x.max())) < 1e-6
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_linear_geglu(cuda, dtype):
     from madm_amd import ops, packing
