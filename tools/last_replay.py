@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel totals of the LAST forward (graph replay) in a rocprofv3 --kernel-trace CSV.
-usage: last_replay.py <kernel_trace.csv | dir> [anchor-substring=image_to_im2col] [detail-regex]"""
+usage: last_replay.py <kernel_trace.csv | dir> [anchor-substring=stem_conv3x3] [detail-regex]"""
 import collections
 import csv
 import glob
@@ -10,7 +10,7 @@ import sys
 p = sys.argv[1]
 if not p.endswith(".csv"):
     p = glob.glob(p + "/**/*kernel_trace.csv", recursive=True)[0]
-anchor = sys.argv[2] if len(sys.argv) > 2 else "image_to_im2col"
+anchor = sys.argv[2] if len(sys.argv) > 2 else "stem_conv3x3"
 rows = sorted(csv.DictReader(open(p)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
 last = rows[idx[-1]:]
