@@ -335,7 +335,8 @@ class LdmRocm(nn.Module):
 
     def forward(self, batched_inputs, input_modal, **kwargs):
         # two stages with a narrow hand-over (the noisy latents), so that a serving loop can capture / schedule them
-        # separately (measured: free-running whole forwards on two streams beat the strict encoder || UNet pipeline)
+        # separately: madm_amd/pipeline.py runs the encoder stage of every batch on one stream and the UNet stages of
+        # consecutive batches side by side on three
         want_grad = torch.is_grad_enabled() and self._wants_grad(batched_inputs, kwargs)
         with torch.no_grad():
             st = self._stage_encode(batched_inputs)
