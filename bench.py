@@ -320,6 +320,7 @@ def main():
 
 
 def run(args, model, call, ldm, rank, world, device, dist, mdist):
+    torch.set_grad_enabled(False)   # inference workloads (with --lora the adapters are trainable: no tape wanted here)
     # eager warm-up: packs weights, sizes workspaces, checks the input range once
     model(*call)
     torch.cuda.synchronize()
