@@ -19,6 +19,7 @@
 //     base registers (+ one XOR for the second k-step) plus an immediate, because the swizzle depends on the halo
 //     COLUMN only (chunk ^ (hx & 7)), not on the linear pixel index.
 // LDS: halo 41 x 1 KiB + 2 weight slots x 16 KiB + 256 B group statistics = 75 008 B -> two blocks per CU.
+#include <atomic>
 #include "conv3x3_common.hpp"
 
 namespace {
@@ -561,15 +562,19 @@ int launch_h16_one(const IgemmP& p0, hipStream_t s) {
     IgemmP p = p0;
     constexpr size_t lds = (size_t)((H16_PIX + 7) / 8) * 1024 + 2 * (size_t)BN * 128 + 32 * sizeof(float2);
     auto kern = conv3x3_h16_kernel<T, BN, FUSE, WIDE>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute is per device: one bit per device id, set once (atomic: host threads may launch concurrently)
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
         if (e != hipSuccess) {
             madm_set_error("conv3x3 (16 x 16 patches): cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
             return MADM_ERR_LAUNCH;
         }
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     const int patchesX = (p.OW + H16_T - 1) / H16_T, patchesY = (p.OH + H16_T - 1) / H16_T;
     p.tilesN = (p.N + BN - 1) / BN;

@@ -20,7 +20,13 @@ def init(backend=None, device=None):
     if world == 1 and not os.environ.get("MADM_FORCE_PROCESS_GROUP"):   # (the switch: the N > 1 code path on one GPU)
         return None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    if "MASTER_PORT" not in os.environ:
+        if world > 1:
+            raise RuntimeError("madm_amd.dist.init: WORLD_SIZE > 1 needs MASTER_PORT (torchrun sets it)")
+        import socket                      # single forced rank: any free port, so two jobs on one host never meet
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {}

@@ -2,8 +2,10 @@
 ``MTMADISE.forward`` eval branch, /root/reference/modeling/meta_arch/mtmadise.py:657-691 -- /255 normalisation,
 pad to a multiple of 64, LoRA adapter of the target modality, backbone('others') -> segmentation head ->
 bilinear upsampling to the padded input size -> crop -> ``[{'sem_seg': [1, K, H, W]}]``; plus the evaluator's
-argmax (evaluation/d2_evaluator.py:106) as a device kernel.  The self-training (train) branch of MTMADISE is
-training policy and out of scope."""
+argmax (evaluation/d2_evaluator.py:106) as a device kernel.  The self-training (train) branch is mtmadise.MTMADISE.
+LoRA contract (mtmadise.py:48-54,115-147): ``'name_rN_aM'`` configs -> one peft-shaped adapter each on to_q / to_k / to_v /
+to_out.0 of every UNet attention, all active after construction, ``ldm_extractor._freeze()`` re-applied (which, with
+``finetune_unet='no'``, freezes the adapters too -- the reference's own behaviour), one adapter selected per pass."""
 import torch
 import torch.nn as nn
 
@@ -43,13 +45,23 @@ class MadmInference(nn.Module):
         ldm._freeze()
 
     def set_lora_adapter(self, state):
-        if len(self.lora_configs) == 0:
+        if len(self.lora_configs) == 0 or state is None:
             return
         if isinstance(state, str):
             state = [state]
         for module in self.backbone.feature_extractor.ldm_extractor.unet.modules():
             if hasattr(module, "_active_adapter"):
                 module._active_adapter = state
+
+    def active_lora_adapter(self):
+        """The adapter list ``set_lora_adapter`` wrote last (None without LoRA): the explicit backward of a recorded pass
+        re-derives the fused LoRA operands and must see the adapter that pass ran with."""
+        if len(self.lora_configs) == 0:
+            return None
+        for module in self.backbone.feature_extractor.ldm_extractor.unet.modules():
+            if hasattr(module, "_active_adapter"):
+                return list(module._active_adapter)
+        return None
 
     @torch.no_grad()
     def forward(self, batched_inputs):

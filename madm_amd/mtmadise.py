@@ -157,7 +157,8 @@ class MTMADISE(MadmInference):
         no_grad_w = ()
         if ldm.vae_decoder_loss and not ldm.final_fuse_vae_decoder_feat:
             no_grad_w = (feats[0].W,)          # the decoder image is ``.detach()``ed (ldm_diffusers.py:196-201)
-        rec = dict(keep=keep, proj_tape=proj_tape, head_tape=head_tape, project=project, B=B, no_grad_w=no_grad_w)
+        rec = dict(keep=keep, proj_tape=proj_tape, head_tape=head_tape, project=project, B=B, no_grad_w=no_grad_w,
+                   adapter=self.active_lora_adapter())     # the backward recomputes the fused LoRA operands: same adapter
         return logits, extra, rec
 
     def _color_latent(self, label, palette):
@@ -278,19 +279,28 @@ class MTMADISE(MadmInference):
 
         names = list(losses.keys())
         params = [p for p in self.parameters() if p.requires_grad]
-        state = dict(model=self, names=names, ctxs=ctxs, rec_s=rec_s, rec_t=rec_t, params=params)
+        zero_ids = set()
+        if self.add_zero_grad:          # :654-655: ``sum(torch.sum(p)) * 0.`` over the LoRA tensors of the other adapters --
+            losses['zero_grad'] = torch.zeros((), device=source.device)     # value 0, gradient 0 (not None) for each of them
+            names.append('zero_grad')
+            zero_ids = {id(p) for p in self.unused_lora_parameters(tmod) if p.requires_grad}
+        state = dict(model=self, names=names, ctxs=ctxs, rec_s=rec_s, rec_t=rec_t, params=params, zero_ids=zero_ids)
         self.last_step = dict(mixed_img=mixed_img, mixed_lbl=mixed_lbl, mixed_seg_weight=mixed_seg_weight,
                               pseudo_label=pseudo_label, pseudo_weight=pseudo_weight, ema_logits=ema_nchw,
                               source_logits=source_logits, target_logits=target_logits)
         outs = _TrainStepFn.apply(state, len(names), *[losses[n] for n in names], *params)
-        result = dict(zip(names, outs))
-        if self.add_zero_grad:
-            result['zero_grad'] = self.add_zero_gead_on_unused_lora(tmod)
-        return result
+        return dict(zip(names, outs))
+
+    def unused_lora_parameters(self, used_modal):
+        """The tensors ``add_zero_gead_on_unused_lora`` sums (mtmadise.py:149-157): every UNet parameter whose name holds
+        'lora' but not the target modality -- the 'default' adapter included."""
+        unet = self.backbone.feature_extractor.ldm_extractor.unet
+        return [p for name, p in unet.named_parameters() if 'lora' in name and used_modal not in name]
 
     def add_zero_gead_on_unused_lora(self, used_modal):
-        unet = self.backbone.feature_extractor.ldm_extractor.unet
-        loss = [torch.sum(p) for name, p in unet.named_parameters() if 'lora' in name and used_modal not in name]
+        """The reference's own formulation through torch autograd (kept for callers outside ``forward_train``, which
+        folds the term into its autograd node: value 0, zero gradients, the tensors count as touched for AdamW)."""
+        loss = [torch.sum(p) for p in self.unused_lora_parameters(used_modal)]
         return sum(loss) * 0.
 
     # ------------------------------------------------------------------ backward of one recorded student pass
@@ -301,6 +311,7 @@ class MTMADISE(MadmInference):
         bb = self.backbone
         gen = bb.feature_extractor
         ldm = gen.ldm_extractor
+        self.set_lora_adapter(rec["adapter"])
         keep = rec["keep"]
         state = keep["state"]
         unet, dtype = keep["unet"], keep["dtype"]
@@ -393,10 +404,22 @@ class _TrainStepFn(torch.autograd.Function):
             if dec_name in ctxs and g.get(dec_name) is not None:
                 dsample = crit.decoder_loss_backward(ctxs[dec_name], g[dec_name])
             ops.GRAD_ZEROS.reset(dlogits.device if dlogits is not None else dsample.device)   # one memset per pass
-            model._backward_pass(rec, dlogits, dsample, add)
+            adapter_now = model.active_lora_adapter()
+            try:
+                model._backward_pass(rec, dlogits, dsample, add)
+            finally:
+                model.set_lora_adapter(adapter_now)
             if sink is not None:
                 sink.flush()
         ops.GRAD_ZEROS.drop()
+        if g.get('zero_grad') is not None:     # zero gradients of the other adapters' LoRA tensors: present, not None
+            for p in params:
+                if id(p) in st["zero_ids"] and id(p) not in touched:
+                    touched.add(id(p))
+                    if sink is None:
+                        acc[id(p)] = torch.zeros_like(p)
+                    else:
+                        early.add(id(p))       # the flat gradient buffer is already zero: only mark the span finished
         st["rec_s"] = st["rec_t"] = None       # free the tapes
         model.last_grad_param_ids = touched    # torch.optim.AdamW skips parameters whose grad is None
         if sink is not None:

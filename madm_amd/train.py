@@ -55,7 +55,16 @@ class MadmTrainer:
         if dist is not None and dist.get_world_size() > 1:
             dist.broadcast(self.opt.flat.flat, src=0)
             torch.autograd.graph.increment_version(self.opt.flat.params)
-            for b in model.buffers():               # DDP broadcasts buffers too (BatchNorm running statistics)
+            # DDP's _sync_module_states covers EVERY parameter and buffer, frozen ones included: the EMA teacher
+            # (ema_sem_seg_head, ema_feature_projections, ema_clip_project_others) is requires_grad=False and, with
+            # detectron2's seed + rank, starts from a different initialisation on every rank otherwise
+            mine = {id(p) for p in self.opt.flat.params}
+            frozen = [p for p in model.parameters() if id(p) not in mine]
+            for p in frozen:
+                dist.broadcast(p.data, src=0)
+            if frozen:
+                torch.autograd.graph.increment_version(frozen)     # packed-operand caches key on the version counter
+            for b in model.buffers():               # (BatchNorm running statistics)
                 dist.broadcast(b, src=0)
         # torch.cuda.amp.GradScaler semantics (only needed for the fp16 compute mode; harmless otherwise)
         self.scale = float(init_scale) if amp else 1.0

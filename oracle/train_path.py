@@ -13,6 +13,14 @@ reg_uncertain, rev_noise_sup + gradually, enable_mixup) on top of the oracle's b
 * ``strong_transform`` restricted to ClassMix (utils/dacs_transforms.py:11-26,100-111; ``color_aug_flag=False`` -- the
   kornia colour jitter / blur is pinned separately, oracle/augment.py).
 
+LoRA branch (``lora_configs`` non-empty, the north_star variant; no shipped config enables it, main.py:613-616,794 does):
+``'name_rN_aM'`` parsing (:48-54), ``set_multi_lora`` (:115-127: one adapter per name on to_k / to_q / to_v / to_out.0, all
+set active, ``ldm_extractor._freeze()`` re-applied), ``set_lora_adapter`` before every pass (:240 'default' for the source
+pass; :286, :310 the target modality for the mixed-image and teacher passes; :672 eval), ``add_zero_gead_on_unused_lora``
+(:149-157, :654-655).  ``ldm_path.OracleLdm._freeze`` restates ldm_diffusers.py:101-121: every extractor parameter frozen, then the
+``finetune_unet`` selection -- so with ``finetune_unet='no'`` the freshly added adapters are frozen as well (that IS the
+reference's behaviour: peft's ``requires_grad=True`` on the adapters is overwritten by the ``_freeze()`` call of :127).
+
 Deviations, all stated: (1) the backbone's hard-coded 512 (``T.Resize((512, 512))``, ``res = 512 // stride``,
 feature_extractor.py:77-79,383) is the parameter ``in_size`` so that the step can run at 64 x 64 in seconds -- the 512
 routing itself is pinned by tests/golden/eval_depth.npz from the reference's class; (2) ``nn.Dropout2d`` draws from torch's
@@ -125,11 +133,20 @@ class OracleMTMADISE(nn.Module):
     def __init__(self, backbone, sem_seg_head, criterion, *, target_modality='Depth', train_palette, ema_alpha=0.999,
                  pseudo_threshold=0.968, vae_decoder_loss='st', vae_decoder_loss_type='L1', vae_decoder_loss_weight=(1.0, 1.0),
                  rev_noise_sup=True, rev_noise_end_iter=5000, rev_noise_gradually=True, denoise_timestep_range=(60, 61),
-                 reg_uncertain=True, blur=True, color_jitter_strength=0.2, color_jitter_probability=0.2):
+                 reg_uncertain=True, blur=True, color_jitter_strength=0.2, color_jitter_probability=0.2,
+                 lora_configs=(), add_zero_grad=False, eval_with_noise=None, init_ema=True):
         super().__init__()
         self.backbone, self.sem_seg_head, self.criterion = backbone, sem_seg_head, criterion
         self.sem_seg_head_sec_modal = self.sem_seg_head                      # cmdise.py:153-156
+        self.lora_configs = dict()                                           # :48-54
+        for lora_config in lora_configs:
+            name, rank, alpha = lora_config.split('_')
+            assert name in {'default', 'Infrared', 'Depth', 'Event'}
+            self.lora_configs[name] = dict(rank=int(rank[1:]), alpha=int(alpha[1:]))
         self.target_modality = target_modality
+        self.add_zero_grad = add_zero_grad
+        if len(self.lora_configs.keys()) != 0:                               # :58-59
+            self.set_multi_lora()
         self.train_iter_index = 0
         self.ema_alpha, self.pseudo_threshold = ema_alpha, pseudo_threshold
         self.vae_decoder_loss, self.vae_decoder_loss_type = vae_decoder_loss, vae_decoder_loss_type
@@ -141,7 +158,38 @@ class OracleMTMADISE(nn.Module):
         pal = list(train_palette)
         self.train_palette = pal + [0] * (768 - len(pal))                    # mtmadise.py:97-99
         self.reg_target_palette = list(self.train_palette)
-        self._inti_ema_weights()
+        self.eval_with_noise = eval_with_noise
+        if init_ema:
+            self._inti_ema_weights()
+
+    def set_multi_lora(self):                                               # :115-127
+        from .sd_modules import LoraConfig
+        ldm = self.backbone.feature_extractor.ldm_extractor
+        for lora_name in self.lora_configs.keys():
+            lora_config = LoraConfig(r=self.lora_configs[lora_name]['rank'], lora_alpha=self.lora_configs[lora_name]['alpha'],
+                                     init_lora_weights="gaussian", target_modules=["to_k", "to_q", "to_v", "to_out.0"])
+            ldm.unet.add_adapter(adapter_config=lora_config, adapter_name=lora_name)
+        ldm.unet.set_adapter(list(self.lora_configs.keys()))
+        ldm._freeze()
+
+    def set_lora_adapter(self, state):                                      # :129-147
+        if len(self.lora_configs.keys()) == 0:
+            return
+        if isinstance(state, str):
+            state = [state]
+        unet = self.backbone.feature_extractor.ldm_extractor.unet
+        for _, module in unet.named_modules():
+            if hasattr(module, '_active_adapter'):                           # isinstance(module, BaseTunerLayer)
+                module._active_adapter = state
+
+    def add_zero_gead_on_unused_lora(self, used_modal):                     # :149-157
+        loss = []
+        unet = self.backbone.feature_extractor.ldm_extractor.unet
+        for name, p in unet.named_parameters():
+            if 'lora' in name and used_modal not in name:
+                loss.append(torch.sum(p))
+        loss = sum(loss) * 0.
+        return loss
 
     def _inti_ema_weights(self):                                            # cmdise.py:307-335
         self.backbone.ema_feature_projections = deepcopy(self.backbone.feature_projections)
@@ -176,6 +224,7 @@ class OracleMTMADISE(nn.Module):
         vae = self.backbone.feature_extractor.ldm_extractor.vae
 
         # source pred (:239-256)
+        self.set_lora_adapter(state='default')                               # :240
         feats, source_out = self.backbone(source, return_unet_final_output=True, input_modal='rgb')
         source_pred = self.sem_seg_head(feats)
         source_color_gt, source_color_gt_mask = OL.convert_label_to_rgb(gt, self.reg_target_palette)
@@ -187,11 +236,13 @@ class OracleMTMADISE(nn.Module):
             mixed_img = torch.cat([OL.one_mix(mix_masks[i], data=torch.stack((source[i], target[i])))[0] for i in range(B)])
 
         # target pred (:284-302)
+        self.set_lora_adapter(state=tmod)                                    # :286
         feats, target_out = self.backbone(mixed_img, return_unet_final_output=True, input_modal='mixed')
         target_pred = self.sem_seg_head(feats)
 
         # teacher (:308-392)
         with torch.no_grad():
+            self.set_lora_adapter(state=tmod)                                # :310
             kw = dict(input_modal='others', ema_forward=True)
             if self.rev_noise_sup and self.train_iter_index <= self.rev_noise_end_iter:
                 t_ = random.randint(self.denoise_timestep_range[0], self.denoise_timestep_range[1])
@@ -223,6 +274,8 @@ class OracleMTMADISE(nn.Module):
                 'pred': target_out['before_vae.decoder'], 'gt': target_color_gt_latent, 'mask': target_color_gt_mask,
                 'loss_weight': self.vae_decoder_loss_weight[1], 'loss_type': self.vae_decoder_loss_type}
         losses = self.criterion(loss_input, loss_target)
+        if self.add_zero_grad:                                               # :654-655
+            losses['zero_grad'] = self.add_zero_gead_on_unused_lora(tmod)
         self.train_iter_index += 1
         self.last_step = dict(mixed_img=mixed_img, mixed_lbl=mixed_lbl, mixed_seg_weight=mixed_seg_weight,
                               pseudo_label=pseudo_label, pseudo_weight=pseudo_weight, ema_logits=ema_logits,
@@ -230,13 +283,36 @@ class OracleMTMADISE(nn.Module):
         return losses
 
 
-def build(vae, unet, cfg, criterion_cls=None, in_size=512, train_palette=None, **kw):
-    """OracleMTMADISE of the Depth configuration on seeded oracle modules (UNet trainable: finetune_unet='all')."""
+def _forward_eval(self, batched_inputs):
+    """mtmadise.py:657-691: the eval branch, with the adapter switch of :672."""
+    assert len(batched_inputs) == 1
+    assert 'modality_type' not in batched_inputs[0].keys()
+    target_modal_type = self.target_modality
+    target_sec_modal = [(x['target_second_modality'] - 0.0) / 255.0 for x in batched_inputs]
+    ori_size = target_sec_modal[0].shape[1:]
+    target_sec_modal = tp.ImageList.from_tensors(target_sec_modal, 64)
+    self.set_lora_adapter(state=target_modal_type)
+    test_input_dict = {'input_modal': 'others'}
+    if self.eval_with_noise is not None:
+        test_input_dict['timestep'] = (self.eval_with_noise, self.eval_with_noise + 1)
+    backbone_feats = self.backbone(target_sec_modal.tensor, **test_input_dict)
+    outputs = self.sem_seg_head_sec_modal(backbone_feats)
+    outputs = F.interpolate(outputs, size=target_sec_modal.tensor.shape[2:], mode='bilinear', align_corners=False)
+    outputs = outputs[:, :, :ori_size[0], :ori_size[1]]
+    self.last_eval_feats = backbone_feats
+    return [{'sem_seg': outputs}]
+
+
+OracleMTMADISE.forward_eval = torch.no_grad()(_forward_eval)
+
+
+def build(vae, unet, cfg, criterion_cls=None, in_size=512, train_palette=None, finetune_unet='all', **kw):
+    """OracleMTMADISE of the Depth configuration on seeded oracle modules (``finetune_unet`` as LdmDiffusers takes it)."""
     ldm = GradLdm(vae, unet, __import__("oracle.sd_modules", fromlist=["x"]).DDPMScheduler(), madm_path.uncond_stand_in(),
                   encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=(), input_range='-1+1',
                   unet_block_indices_type='after', vae_decoder_loss=cfg["vae_decoder_loss"])
-    for p in vae.parameters():
-        p.requires_grad = False
+    ldm.finetune_unet = finetune_unet
+    ldm._freeze()                                                            # LdmDiffusers.__init__ (ldm_diffusers.py:77)
     gen = madm_path.PromptTimeGenerator(ldm)
     backbone = TrainBackbone(gen, cfg, in_size=in_size)
     head = madm_path.OracleHead(cfg)

@@ -90,10 +90,26 @@ def main_eval():
         if only and name not in only:
             continue
         cfg = madm_path.cfg_by_name(case["cfg"])
-        backbone, head = madm_path.build_reference_eval_model(ns, vae, unet, cfg)
+        if case.get("lora_configs"):      # own modules: set_multi_lora wraps the attention projections in place
+            vae_c, unet_c = build_oracle(lora=False)
+        else:
+            vae_c, unet_c = vae, unet
+        backbone, head = madm_path.build_reference_eval_model(ns, vae_c, unet_c, cfg)
         init_eval_params(backbone, head)
         t0 = time.time()
-        sem_seg, feats = madm_path.eval_forward(backbone, head, eval_image(case["H"], case["W"]))
+        if case.get("lora_configs"):
+            # the meta-architecture's eval branch (mtmadise.py:657-691) incl. the LoRA contract of :48-54,115-147,672 as
+            # oracle/train_path.OracleMTMADISE restates it, over the REFERENCE's backbone / head classes
+            from oracle import train_path
+            from golden_util import seed_lora_
+            meta = train_path.OracleMTMADISE(backbone, head, None, target_modality='Depth', train_palette=[0, 0, 0],
+                                             lora_configs=case["lora_configs"], init_ema=False).eval()
+            seed_lora_(unet_c)
+            sem_seg = meta.forward_eval([{'target_second_modality': eval_image(case["H"], case["W"])}])[0]['sem_seg']
+            feats = meta.last_eval_feats
+            assert all(m._active_adapter == ['Depth'] for m in unet_c.modules() if hasattr(m, '_active_adapter'))
+        else:
+            sem_seg, feats = madm_path.eval_forward(backbone, head, eval_image(case["H"], case["W"]))
         out = {"sem_seg": sem_seg[:, :, ::4, ::4].contiguous().numpy(),
                "sem_seg_shape": np.array(sem_seg.shape, dtype=np.int64),
                "labels": sem_seg[0].argmax(dim=0).to(torch.uint8).numpy(),
@@ -134,13 +150,14 @@ def build_train_oracle(reference=True, variant="train_depth"):
     """OracleMTMADISE of the Depth config at TRAIN_CASE size; ``reference``: the REFERENCE's DAFormerHead class and
     CmdiseCriterion (this container), else the oracle's restatements (anywhere)."""
     from oracle import madm_path, train_path
-    from golden_util import TRAIN_CASE, TRAIN_VARIANTS, train_palette, train_dropout_scales
+    from golden_util import TRAIN_CASE, TRAIN_VARIANTS, train_palette, train_dropout_scales, model_args, prepare_lora_
     cfg = madm_path.DEPTH_CFG
     vae, unet = build_oracle(lora=False)
     crit = train_path.reference_criterion() if reference else None
     model = train_path.build(vae, unet, cfg, criterion_cls=crit, in_size=TRAIN_CASE["size"],
                              train_palette=train_palette(TRAIN_CASE["K"]), pseudo_threshold=TRAIN_CASE["pseudo_threshold"],
-                             **TRAIN_VARIANTS[variant])
+                             finetune_unet=TRAIN_VARIANTS[variant].get("finetune_unet", "all"), **model_args(variant))
+    prepare_lora_(unet, variant)
     if reference:
         ns = ref_driver.load_modeling()
         n = len(cfg["out_features"])
@@ -151,10 +168,6 @@ def build_train_oracle(reference=True, variant="train_depth"):
         head.dropout = train_path.FixedDropout2d()
         model.sem_seg_head = model.sem_seg_head_sec_modal = head
     init_eval_params(model.backbone, model.sem_seg_head)
-    for m in (model.backbone.feature_extractor.ldm_extractor.unet.conv_norm_out,
-              model.backbone.feature_extractor.ldm_extractor.unet.conv_out):      # exclude_unused_params (ldm_diffusers.py:123-141)
-        for p in m.parameters():
-            p.requires_grad = False
     model._inti_ema_weights()           # teacher = copy of the initialised student (cmdise.py:307-335)
     model.train()
     model.backbone.feature_extractor.ldm_extractor.vae.eval()
@@ -234,13 +247,14 @@ def main_labels():
 
 
 if __name__ == "__main__":
-    if not sys.argv[1:] or any(a.startswith("train_") for a in sys.argv[1:]):
+    args = sys.argv[1:]
+    if not args or any(a.startswith("train_") for a in args):
         main_train()
-    if "labels" in sys.argv[1:] or not sys.argv[1:]:
+    if not args or "labels" in args:
         main_labels()
-    if "slide_s345" in sys.argv[1:] or not sys.argv[1:]:
+    if not args or "slide_s345" in args:
         main_slide()
-    if not sys.argv[1:] or any(a in CASES for a in sys.argv[1:]):
+    if not args or any(a in CASES for a in args):
         main()
-    if not sys.argv[1:] or any(a in EVAL_CASES for a in sys.argv[1:]):
+    if not args or any(a in EVAL_CASES for a in args):
         main_eval()

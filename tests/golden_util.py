@@ -35,10 +35,19 @@ def load_golden(name):
 def add_lora(unet, LoraConfig, seed=WEIGHT_SEED):
     """Same adapters / values as tests/golden/gen_golden.py::add_lora, for any module tree with the
     peft-shaped names (oracle or madm_amd)."""
-    from madm_amd import weights
     unet.add_adapter(LoraConfig(r=8, lora_alpha=8), "default")
     unet.add_adapter(LoraConfig(r=8, lora_alpha=16), "Depth")
     unet.set_adapter(["default", "Depth"])
+    seed_lora_(unet, seed)
+    for m in unet.modules():
+        if hasattr(m, "_active_adapter"):
+            m._active_adapter = ["Depth"]
+
+
+def seed_lora_(unet, seed=WEIGHT_SEED):
+    """Name-keyed seeded values for every LoRA tensor already present in ``unet`` (peft's own init has B = 0: the
+    adapters would be no-ops and their A gradients zero)."""
+    from madm_amd import weights
     with torch.no_grad():
         for name, p in unet.named_parameters():
             if ".lora_" in name:
@@ -47,13 +56,13 @@ def add_lora(unet, LoraConfig, seed=WEIGHT_SEED):
                 g = weights._gen(seed, "unet." + name)
                 gain = 0.1 if ".lora_B." in name else 1.0
                 p.copy_((gain * torch.randn(p.shape, generator=g) / (p.shape[1] ** 0.5)).to(p.device))
-    for m in unet.modules():
-        if hasattr(m, "_active_adapter"):
-            m._active_adapter = ["Depth"]
 
 
 def tap_subset(name, t):
     return t[:, ::CH_STRIDE_FULL] if name.startswith("full") else t
+
+
+LORA_CONFIGS = ['default_r8_a8', 'Depth_r8_a16']
 
 
 # ---- full inference forward (config 3): backbone + head + eval post-processing ---------------------------------
@@ -65,6 +74,10 @@ EVAL_CASES = {
     # the shipped RGB->Infrared configuration (K = 9, FMB test images are resized to 512 x 512 by the mapper,
     # config_files/common/data/cityscapes_rgb_to_fmb_9_infrared_semseg.py:43); RGB->Event is the Depth graph (K = 11)
     "eval_infrared": dict(cfg="INFRARED", H=512, W=512),
+    # the Depth configuration with ``--lora_configs default_r8_a8 Depth_r8_a16`` (main.py:613-616,794) through the
+    # meta-architecture's eval branch: 'name_rN_aM' parsing, set_multi_lora, set_lora_adapter(target) (mtmadise.py:48-54,
+    # 115-147,672); LoRA values seeded by ``seed_lora_``
+    "eval_depth_lora": dict(cfg="DEPTH", H=512, W=512, lora_configs=LORA_CONFIGS),
 }
 
 
@@ -109,7 +122,37 @@ TRAIN_VARIANTS = {
     # mtmadise_cityscapes_rgb_to_event_11.py:43-58: source-only decoder loss with weight 20, teacher noise step 50
     "train_event": dict(vae_decoder_loss='s', vae_decoder_loss_weight=[20.0], denoise_timestep_range=[50, 51],
                         rev_noise_end_iter=8000),
+    # --lora_configs default_r8_a8 Depth_r8_a16 --add_zero_grad on the Depth config (finetune_unet='all', the model
+    # config's value, mtmadise_multi_lora.py:34): base weights AND both adapters train; 'default' gets its gradient from the
+    # source pass, 'Depth' from the mixed-image pass (mtmadise.py:240,286)
+    "train_depth_lora": dict(vae_decoder_loss='st', vae_decoder_loss_weight=[1.0, 1.0], denoise_timestep_range=[60, 61],
+                             rev_noise_end_iter=5000, lora_configs=LORA_CONFIGS, add_zero_grad=True, finetune_unet='all'),
+    # adapters only: finetune_unet='no' (main.py:558-559) freezes the UNet INCLUDING the adapters (ldm_diffusers.py:101-104
+    # runs after peft marked them trainable, mtmadise.py:127), so the harness re-enables requires_grad on the LoRA tensors
+    # (``lora_trainable``: peft's mark_only_lora_as_trainable convention, the north_star's LoRA mode -- NOT a reference
+    # flag); a third adapter that no pass uses receives the zero gradient of add_zero_gead_on_unused_lora
+    "train_depth_lora_only": dict(vae_decoder_loss='st', vae_decoder_loss_weight=[1.0, 1.0], denoise_timestep_range=[60, 61],
+                                  rev_noise_end_iter=5000, lora_configs=LORA_CONFIGS + ['Event_r4_a4'], add_zero_grad=True,
+                                  finetune_unet='no', lora_trainable=True),
 }
+HARNESS_KEYS = ("finetune_unet", "lora_trainable")     # not MTMADISE arguments
+
+
+def model_args(variant):
+    return {k: v for k, v in TRAIN_VARIANTS[variant].items() if k not in HARNESS_KEYS}
+
+
+def prepare_lora_(unet, variant):
+    """After construction of the meta-architecture: seeded LoRA values; ``lora_trainable`` variants mark the adapters
+    trainable again."""
+    v = TRAIN_VARIANTS[variant]
+    if not v.get("lora_configs"):
+        return
+    seed_lora_(unet)
+    if v.get("lora_trainable"):
+        for n, p in unet.named_parameters():
+            if ".lora_" in n:
+                p.requires_grad = True
 
 
 def train_inputs(B, size, K, **_):
@@ -151,6 +194,7 @@ def grad_summary(named_grads, full_max):
         g = g.detach().double().cpu()
         names.append(n)
         rows.append([g.norm().item(), (g * grad_probe(n, g.shape).double()).sum().item()])
-        if g.numel() <= full_max and ".unet." not in n:
+        if g.numel() <= full_max and (".unet." not in n or (".lora_" in n and (".down_blocks.0.attentions.0." in n
+                                                                              or ".mid_block." in n))):
             full[n] = g.float()
     return names, np.array(rows, dtype=np.float64), full

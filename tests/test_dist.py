@@ -127,6 +127,10 @@ class _TinyTrainModel(torch.nn.Module):
         unet.up = torch.nn.ParameterDict({"weight": mk(2500)})
         self.backbone.unet = unet
         self.sem_seg_head = torch.nn.ParameterDict({"weight": mk(1500), "bias": mk(11)})
+        # the EMA teacher: requires_grad=False parameters (cmdise.py:307-335) that DDP's start-up broadcast covers too
+        self.ema_sem_seg_head = torch.nn.ParameterDict({"weight": mk(1500), "bias": mk(11)})
+        for p in self.ema_sem_seg_head.parameters():
+            p.requires_grad = False
 
 
 def _trainer_worker(rank, world, port, q):
@@ -142,7 +146,7 @@ def _trainer_worker(rank, world, port, q):
                 p.add_(1.0)
     tr = MadmTrainer(model, lr=1e-3, weight_decay=0.05, dist=d)
     tr.reducer.bucket = 2048                        # small buckets so that several collectives start during the "backward"
-    params0 = tr.opt.flat.flat.clone()
+    params0 = torch.cat([tr.opt.flat.flat.clone()] + [p.detach().flatten() for p in model.ema_sem_seg_head.parameters()])
     order = [n for n, _ in model.named_parameters()]
     flat_names = [dict((id(p), n) for n, p in model.named_parameters())[id(p)] for p in tr.opt.flat.params]
     # the explicit backward finishes gradients back to front: head, up, res.conv1, conv_in, then the late tails
@@ -179,7 +183,9 @@ def test_trainer_broadcast_flat_order_and_overlapped_reduce_two_rank_gloo():
         assert p.exitcode == 0
     (_, p0, g0, names0, during0, _), (_, p1, g1, names1, during1, _) = res
     p0, g0, p1, g1 = (torch.from_numpy(a) for a in (p0, g0, p1, g1))
-    assert torch.equal(p0, p1)                                        # broadcast: identical start
+    assert torch.equal(p0, p1)                                        # broadcast: identical start, frozen teacher included
+    ref_teacher = torch.cat([p.detach().flatten() for p in _TinyTrainModel().ema_sem_seg_head.parameters()])
+    assert torch.equal(p1[-ref_teacher.numel():], ref_teacher)        # ... and it is rank 0's (unperturbed) teacher
     assert names0 == names1 and names0[:3] == ["backbone.clip_project_rgb.prompt_embed", "backbone.unet.time_embedding.weight",
                                                 "backbone.unet.res.time_emb_proj.weight"]
     assert names0[3:] == ["backbone.unet.conv_in.weight", "backbone.unet.res.conv1.weight", "backbone.unet.up.weight",

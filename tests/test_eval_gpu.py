@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from golden_util import EVAL_CASES, eval_image, init_eval_params, load_golden
+from golden_util import EVAL_CASES, eval_image, init_eval_params, load_golden, seed_lora_
 from util import to_tokens, from_tokens, rel_err, bf16_round
 
 pytestmark = pytest.mark.gpu
@@ -124,7 +124,7 @@ def test_daformer_head_small(cuda, dtype):
     assert got.shape == want.shape and e < (3e-5 if dtype == torch.float32 else 3e-2), f"{e:.2e} {l2:.2e}"
 
 
-def _build_product(cfg_name, dtype):
+def _build_product(cfg_name, dtype, lora_configs=()):
     from madm_amd.ldm_rocm import LdmRocm
     from madm_amd.backbone import BasePromptTimeGenerator, AttentionFeatureExtractorBackbone
     from madm_amd.head import DAFormerHead
@@ -144,21 +144,35 @@ def _build_product(cfg_name, dtype):
                         channels=256, dropout_ratio=0.1, num_classes=cfg["num_classes"], norm_cfg=dict(type='BN'),
                         align_corners=False, decoder_params=madm_path.head_decoder_params())
     init_eval_params(backbone, head)
-    model = MadmInference(backbone.cuda(), head.cuda(), target_modality="Depth").eval()
+    model = MadmInference(backbone.cuda(), head.cuda(), target_modality="Depth", lora_configs=lora_configs).eval()
+    if lora_configs:
+        seed_lora_(ldm.unet)
     return model
 
 
-@pytest.mark.parametrize("name", ["eval_s345", "eval_depth", "eval_infrared"])
+@pytest.mark.parametrize("name", ["eval_s345", "eval_depth", "eval_infrared", "eval_depth_lora"])
 @pytest.mark.parametrize("dtype", DTYPES + [torch.float16], ids=["f32", "bf16", "f16"])
 def test_eval_forward_golden(cuda, name, dtype):
     """MTMADISE eval forward (mtmadise.py:657-691) end to end vs the vectors of the reference's own classes."""
     from madm_amd.meta_arch import MadmInference
     case = EVAL_CASES[name]
     gold = load_golden(name)
-    model = _build_product(case["cfg"], dtype)
+    model = _build_product(case["cfg"], dtype, lora_configs=case.get("lora_configs", ()))
     img = eval_image(case["H"], case["W"])
+    unet = model.backbone.feature_extractor.ldm_extractor.unet
+    if case.get("lora_configs"):      # the 'name_rN_aM' contract (mtmadise.py:48-54,115-127): parsed, all adapters active
+        assert model.lora_configs == {'default': dict(rank=8, alpha=8), 'Depth': dict(rank=8, alpha=16)}
+        assert model.active_lora_adapter() == ['default', 'Depth']
+        wrapped = [n for n, m in unet.named_modules() if hasattr(m, "_active_adapter")]
+        assert len(wrapped) == 16 * 2 * 4 and all(n.endswith(("to_q", "to_k", "to_v", "to_out.0")) for n in wrapped)
+        assert sum(p.numel() for n, p in unet.named_parameters() if ".lora_" in n) == 2 * 199296 * 8
+        assert not any(p.requires_grad for p in unet.parameters())       # finetune_unet='no': _freeze() froze the adapters too
     out = model([{"target_second_modality": img}])
     torch.cuda.synchronize()
+    if case.get("lora_configs"):      # :672 selected the target modality's adapter
+        assert model.active_lora_adapter() == ['Depth']
+        base = load_golden("eval_depth")["sem_seg"]
+        assert rel_err(out[0]["sem_seg"].cpu()[:, :, ::4, ::4], base)[1] > 0.02, "the adapter must change the result"
     sem = out[0]["sem_seg"].cpu()
     assert tuple(sem.shape) == tuple(gold["sem_seg_shape"].tolist())
     e, l2 = rel_err(sem[:, :, ::4, ::4], gold["sem_seg"])
