@@ -87,6 +87,11 @@ def parse():
                          "MTMADISE training step (source + target + teacher pass, backward, clip, AdamW, EMA), RGB->Depth "
                          "config, full UNet fine-tune -- both informational")
     ap.add_argument("--color-aug", action="store_true", help="train workload: colour jitter + blur of strong_transform")
+    ap.add_argument("--no-alt-dtype", action="store_true",
+                    help="skip the second timed run of the extract workload in the other 16-bit type (alt_dtype in the line)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="--gpus N without a torchrun environment: spawn the N ranks, have each print its RANK / LOCAL_RANK / "
+                         "WORLD_SIZE and exit before anything touches a GPU (launcher test)")
     return ap.parse_args()
 
 
@@ -195,46 +200,54 @@ def run_train(args, rank, world, device, dist, mdist):
 
 
 def kernel_profile(model, inputs):
-    """Eager pass with HIP events around every MFMA-kernel launch (events recorded on the launch
-    stream).  An event pair costs marker + dispatch latency on top of the kernel it brackets; that cost is
-    measured live with EMPTY brackets on the same stream and subtracted per launch, so the figures line up
-    with rocprofv3's kernel timestamps (profiles/README.md).
-    Returns ({kernel: (launches, total_ms, algorithmic_flops, algorithmic_bytes)}, overhead_us)."""
+    """Two eager passes with HIP events around every MFMA-kernel launch (events recorded on the launch stream).
+
+    * raw: one event pair per launch -- the bracket holds the kernel plus the marker / dispatch cost of the pair;
+    * differenced (conv / GEMM launches): the launch is issued three times as [K] [K K] between three events
+      (ops.PROFILE_DIFF); bracket 2 - bracket 1 = one launch with the pair's constant cost cancelled.  This replaces
+      round 2's "empty bracket" overhead estimate, which over-corrected (8.6 us subtracted per launch where
+      rocprofv3's timestamps implied ~4.6).  Launches without a differenced figure (attention) keep the raw one.
+
+    Returns {kernel: (launches, raw_ms, algorithmic_flops, algorithmic_bytes, differenced_ms)}."""
     from madm_amd import ops
     for _ in range(2):
         model(*inputs)
     torch.cuda.synchronize()
-    ops.PROFILE = []
-    try:
-        model(*inputs)
-        torch.cuda.synchronize()
-        rec = ops.PROFILE
-    finally:
-        ops.PROFILE = None
-    empty = []
-    for _ in range(64):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        b.record()
-        empty.append((a, b))
-    torch.cuda.synchronize()
-    gaps = sorted(a.elapsed_time(b) for a, b in empty)
-    overhead_ms = gaps[len(gaps) // 2]
+
+    def one_pass(diff):
+        ops.PROFILE, ops.PROFILE_DIFF = [], diff
+        try:
+            model(*inputs)
+            torch.cuda.synchronize()
+            return ops.PROFILE
+        finally:
+            ops.PROFILE, ops.PROFILE_DIFF = None, False
+
+    raw = one_pass(False)
+    dif = one_pass(True)
+    assert [r[0] for r in raw] == [r[0] for r in dif]
     agg = {}
-    for name, flops, e0, e1, _, nbytes in rec:
-        n, ms, fl, by = agg.get(name, (0, 0.0, 0.0, 0))
-        agg[name] = (n + 1, ms + max(e0.elapsed_time(e1) - overhead_ms, 1e-4), fl + flops, by + nbytes)
-    return agg, overhead_ms * 1e3
+    for (name, flops, e0, e1, _, nbytes, _p), (_, _, d0, d1, _, _, dp) in zip(raw, dif):
+        n, ms, fl, by, dms = agg.get(name, (0, 0.0, 0.0, 0, 0.0))
+        t_raw = e0.elapsed_time(e1)
+        t_dif = max(d1.elapsed_time(dp.e2) - d0.elapsed_time(d1), 1e-4) if dp.e2 is not None else t_raw
+        agg[name] = (n + 1, ms + t_raw, fl + flops, by + nbytes, dms + t_dif)
+    return agg
 
 
 def pmc_traffic(kernel, workload):
     """Mean HBM bytes per launch of ``kernel`` from the committed PMC passes of this same command
     (tools/pmc.sh -> tools/pmc_report.py --json; counters cannot be read from inside the process)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"pmc_bench_{workload}.json")
+    rel = os.path.join("profiles", f"pmc_bench_{workload}.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), rel)
     try:
-        return json.load(open(path))["kernels"][kernel]["hbm_bytes_per_launch"]
+        raw = open(path, "rb").read()
+        import hashlib
+        return (json.loads(raw)["kernels"][kernel]["hbm_bytes_per_launch"],
+                f"{rel}@sha256:{hashlib.sha256(raw).hexdigest()[:12]} (committed rocprofv3 --pmc passes of this command, "
+                "tools/pmc.sh; counters cannot be read from inside the process)")
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def usable_cores():
@@ -328,7 +341,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
 
     prof = None
     if rank == 0 and not args.no_kernel_profile:
-        prof, event_overhead_us = kernel_profile(model, call)
+        prof = kernel_profile(model, call)
 
     first_stream = None      # set when the steps run on streams of their own
     staged = args.workload == "extract" and args.pipeline > 0 and not args.no_graph
@@ -436,7 +449,36 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
     if dist is not None:
         dist.barrier()
         elapsed = mdist.max_over_ranks(elapsed, dist, device)
+    alt = None
+    conc = None
     if staged:
+        conc = pipe.concurrency_probe()
+        if world == 1 and args.dtype in ("f16", "bf16") and not args.no_alt_dtype and not args.lora:
+            # configs[1] says bf16, the default arithmetic is f16 (the reference's autocast type): the other 16-bit type is
+            # timed in the same process with the same launch strategy so that both are driver-visible
+            other = "bf16" if args.dtype == "f16" else "f16"
+            from madm_amd.ldm_rocm import LdmRocm
+            m2 = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=[],
+                         input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
+                         compute_dtype={"bf16": torch.bfloat16, "f16": torch.float16}[other], weights='synthetic', seed=0,
+                         device=device)
+            m2(*call)
+            torch.cuda.synchronize()
+            m2.check_input_range = False
+            pipe2 = StagedExtractor(m2, call[0], unet_streams=args.pipeline)
+            for _ in range(args.warmup):
+                pipe2.submit()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pipe2.submit()
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            alt = {other: {"value": round(args.batch * args.steps / el2, 3), "unit": "images/s",
+                           "ms_per_step": round(1e3 * el2 / args.steps, 4),
+                           "note": "same process, same staged pipeline and step counts, run after the headline region on "
+                                   "streams created later"}}
+            del pipe2, m2
         gs_, _, sts_ = capture_whole_forward(1, 1)
         serial_ms = serial_reference(gs_[0], sts_[0])
 
@@ -484,19 +526,30 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
             "serial_images_per_s_per_gpu": None if serial_ms is None else round(args.batch / serial_ms * 1e3, 3),
             "whole_path_roofline_frac": round(value / world * alg / (peak * 1e12), 4),
         }
+        if alt is not None:
+            out["alt_dtype"] = alt
+        if conc is not None:
+            out["config"]["pipeline_concurrency"] = {
+                "unet_side_by_side_over_serial": round(conc, 3),
+                "note": f"{args.pipeline} UNet graphs on their {args.pipeline} streams / ({args.pipeline} x one alone), probed after "
+                        "the timed region; ~1.0 would mean the streams share a hardware pipe"}
         if prof:
-            dom = max(prof.items(), key=lambda kv: kv[1][1])
-            name, (n, ms, fl, by) = dom
+            dom = max(prof.items(), key=lambda kv: kv[1][4])
+            name, (n, ms_raw, fl, by, ms) = dom
             achieved = fl / (ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(name, args.workload)
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                               "traffic": pmc_traffic(name, args.workload),
+                               "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes": by // n if by else None,
                                "launches_per_step": n, "kernel_ms_per_step": round(ms, 4),
-                               "event_pair_overhead_us_subtracted": round(event_overhead_us, 2)}
-            out["kernels"] = {k: {"launches": v[0], "ms": round(v[1], 4),
-                                  "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] > 0 else None}
-                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+                               "timing": "HIP events on the launch stream, differenced brackets [K] [K K] (no overhead "
+                                         "estimate subtracted); frac_events_raw = one plain event pair per launch",
+                               "kernel_ms_per_step_events_raw": round(ms_raw, 4),
+                               "frac_events_raw": round(fl / (ms_raw * 1e-3) / 1e12 / peak, 4)}
+            out["kernels"] = {k: {"launches": v[0], "ms": round(v[4], 4), "ms_events_raw": round(v[1], 4),
+                                  "tflops": round(v[2] / (v[4] * 1e-3) / 1e12, 2) if v[4] > 0 else None}
+                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1][4])}
         if world == 1 and not args.no_cpu_baseline and args.workload == "extract":
             out["cpu_baseline"] = cpu_baseline(args.size)
         emit(out)
@@ -517,7 +570,38 @@ def emit(out):
         os.write(_RESULT_FD, line)
 
 
+def launch_ranks():
+    """``python bench.py --gpus N`` (N > 1) outside a torchrun environment: start the N ranks as child processes through
+    ``torch.distributed.run`` BEFORE this process touches a GPU (a process that initialised the GPU must never exec; the
+    parent only counts devices, which does not initialise it) and relay rank 0's single JSON line."""
+    import socket
+    import subprocess
+    n = _early_int_flag("--gpus", 1)
+    dry = "--dry-launch" in sys.argv
+    visible = torch.cuda.device_count()
+    if not dry and visible < n:
+        raise SystemExit(f"bench.py: {n} GPUs requested, {visible} visible")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [l for l in proc.stdout.read().decode().splitlines() if l.startswith("{")]
+    rc = proc.wait()
+    for l in lines:
+        print(l)
+    sys.stdout.flush()
+    raise SystemExit(rc if rc else (0 if lines else 1))
+
+
 if __name__ == "__main__":
+    if _early_int_flag("--gpus", 1) > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks()
+    if "--dry-launch" in sys.argv:     # a spawned rank of the launcher test: report the environment, touch nothing
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+        sys.exit(0)
     # everything else that writes to file descriptor 1 (the RCCL version banner at process-group start / teardown, library
     # chatter) goes to stderr: rank 0's stdout carries exactly one line
     sys.stdout.flush()

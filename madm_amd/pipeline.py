@@ -12,6 +12,9 @@ own output tensors; a slot's encoder waits until the slot's previous UNet has fi
 Same kernels, same per-batch results as ``LdmRocm.forward`` (tests/test_parity_gpu.py::test_staged_pipeline_matches_forward);
 only the order in which the GPU sees the launches changes.
 """
+import os
+import warnings
+
 import torch
 
 from . import ops
@@ -22,6 +25,12 @@ class StagedExtractor:
         assert unet_streams >= 1
         self.ldm = ldm
         self.k = int(unet_streams)
+        # the k + 1 streams overlap only when each sits on a hardware queue (and pipe) of its own: the runtime multiplexes
+        # HIP streams onto GPU_MAX_HW_QUEUES queues (default 4) in creation order and reads the variable once, at start-up
+        q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+        if q < self.k + 1:
+            warnings.warn(f"StagedExtractor: {self.k + 1} streams on GPU_MAX_HW_QUEUES={q} hardware queues -- streams will "
+                          "share queues and serialise; export GPU_MAX_HW_QUEUES>=%d before the process starts" % (self.k + 1))
         dev = batched_inputs['img'].device
         self.s_enc = torch.cuda.Stream(device=dev)
         self.s_unet = [torch.cuda.Stream(device=dev) for _ in range(self.k)]
@@ -76,6 +85,28 @@ class StagedExtractor:
             self.unet_graphs[j].replay()
             self.done[j].record(s)
         return self.outs[j], self.done[j]
+
+    def concurrency_probe(self, reps=3):
+        """Detects streams that share a hardware pipe: time of the k UNet graphs side by side on their k streams over k
+        times the time of one of them alone (1.0 = fully serialised, ~0.6 measured for k = 3 on four free pipes: 3.7 vs
+        5.7 ms per UNet).  Wall clock around device synchronisations; call it outside timed regions."""
+        import time
+        dev = self.s_enc.device
+
+        def timed(js):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for j in js:
+                    with torch.cuda.stream(self.s_unet[j]):
+                        self.unet_graphs[j].replay()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / reps
+
+        timed(range(self.k))
+        one = min(timed([j]) for j in range(self.k))
+        side = timed(range(self.k))
+        return side / (self.k * one)
 
     def fork(self, stream=None):
         """The pipeline's streams start after everything queued on ``stream`` (default: the current one)."""

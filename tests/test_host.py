@@ -243,3 +243,25 @@ def test_ldm_rocm_keeps_ldm_diffusers_class_surface():
         assert sig[1:1 + len(ref_args)] == ref_args
     with pytest.raises(NotImplementedError):
         LdmRocm("", [], [5, 8, 11], [], concat_pixel_shuffle=True, weights="synthetic", device="cpu")
+
+
+def test_bench_gpus_n_spawns_the_ranks_before_touching_a_gpu():
+    """``python bench.py --gpus 2`` outside a torchrun environment starts 2 child ranks through torch.distributed.run with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (--dry-launch: the ranks report and exit before any GPU call); without
+    enough visible devices the launcher refuses with a clear message instead of running one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ranks = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda d: d["RANK"])
+    assert [d["RANK"] for d in ranks] == ["0", "1"] and [d["LOCAL_RANK"] for d in ranks] == ["0", "1"]
+    assert all(d["WORLD_SIZE"] == "2" and d["MASTER_ADDR"] == "127.0.0.1" and d["MASTER_PORT"] for d in ranks)
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                           timeout=300, env=env)
+        assert r.returncode != 0 and "2 GPUs requested" in r.stderr and "visible" in r.stderr

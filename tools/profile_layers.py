@@ -36,7 +36,7 @@ def main():
     rec = ops.PROFILE
     ops.PROFILE = None
     rows = {}
-    for name, flops, a, b, desc, _ in rec:
+    for name, flops, a, b, desc, _, _ in rec:
         k = (name, desc)
         n, ms, fl = rows.get(k, (0, 0.0, 0.0))
         rows[k] = (n + 1, ms + a.elapsed_time(b), fl + flops)

@@ -51,7 +51,7 @@ def main():
         m(*call)
         torch.cuda.synchronize()
         rec, ops.PROFILE = ops.PROFILE, None
-        return [(name, desc, e0.elapsed_time(e1) * 1e3) for name, _, e0, e1, desc, _ in rec if not name.startswith("attn")]
+        return [(name, desc, e0.elapsed_time(e1) * 1e3) for name, _, e0, e1, desc, _, _ in rec if not name.startswith("attn")]
 
     # results[launch index][(tile, sk)] = [us...]; the launch sequence is identical in every forward
     base = profiled()
