@@ -87,6 +87,10 @@ def parse():
                          "MTMADISE training step (source + target + teacher pass, backward, clip, AdamW, EMA), RGB->Depth "
                          "config, full UNet fine-tune -- both informational")
     ap.add_argument("--color-aug", action="store_true", help="train workload: colour jitter + blur of strong_transform")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "rs_ag"],
+                    help="train workload, N > 1: gradient exchange per bucket (dist.GradBucketReducer): all_reduce, or "
+                         "reduce_scatter + all_gather (one direct exchange per peer on the xGMI mesh)")
+    ap.add_argument("--wire", default="f32", choices=["f32", "bf16", "f16"], help="train workload: gradient wire type")
     ap.add_argument("--no-alt-dtype", action="store_true",
                     help="skip the second timed run of the extract workload in the other 16-bit type (alt_dtype in the line)")
     ap.add_argument("--dry-launch", action="store_true",
@@ -161,7 +165,8 @@ def run_train(args, rank, world, device, dist, mdist):
     from madm_amd.train import MadmTrainer
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     model = build_train_model(dtype, device, args.color_aug)
-    trainer = MadmTrainer(model, lr=5e-6, weight_decay=0.05, grad_clip=0.01, dist=dist, amp=True)
+    trainer = MadmTrainer(model, lr=5e-6, weight_decay=0.05, grad_clip=0.01, dist=dist, amp=True, exchange=args.exchange,
+                          wire_dtype={"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}[args.wire])
     data = train_inputs(args.batch, args.size, device)
     for _ in range(max(1, args.warmup)):
         losses, norm, stepped = trainer.run_step(data)
@@ -188,7 +193,8 @@ def run_train(args, rank, world, device, dist, mdist):
                                       f"({n_param / 1e6:.1f} M trainable parameters), colour augmentation "
                                       + ("on" if args.color_aug else "off"),
                           "global_batch": args.batch * world,
-                          "parallelism": f"dp{world}: gradient all-reduce(mean) over the flat fp32 buffer" if world > 1 else "dp1",
+                          "parallelism": (f"dp{world}: gradient mean over the flat buffer, {args.exchange}, wire {args.wire}, "
+                                          "256 MB buckets started during the backward") if world > 1 else "dp1",
                           "launch": "eager"},
                "allreduce_exposed_ms": trainer.last_allreduce_exposed_ms,
                "allreduce_started_during_backward_frac": trainer.last_overlap_frac,
@@ -465,7 +471,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
             m2(*call)
             torch.cuda.synchronize()
             m2.check_input_range = False
-            pipe2 = StagedExtractor(m2, call[0], unet_streams=args.pipeline)
+            pipe2 = StagedExtractor(m2, call[0], unet_streams=args.pipeline, streams=pipe.streams)
             for _ in range(args.warmup):
                 pipe2.submit()
             torch.cuda.synchronize()
@@ -476,8 +482,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
             el2 = time.perf_counter() - t1
             alt = {other: {"value": round(args.batch * args.steps / el2, 3), "unit": "images/s",
                            "ms_per_step": round(1e3 * el2 / args.steps, 4),
-                           "note": "same process, same staged pipeline and step counts, run after the headline region on "
-                                   "streams created later"}}
+                           "note": "same process, same staged pipeline, streams and step counts, run after the headline region"}}
             del pipe2, m2
         gs_, _, sts_ = capture_whole_forward(1, 1)
         serial_ms = serial_reference(gs_[0], sts_[0])

@@ -48,6 +48,13 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restri
         float s = 0.f;
         for (int k = 0; k < K; ++k) s += expf(x[(size_t)k * HW] - m);
         const float p = 1.0f / s;            // exp(0) / sum
+        // the reference takes the max / argmax of the f32 PROBABILITIES (mtmadise.py:340-341): logits one ulp apart
+        // round to equal probabilities and the FIRST of them wins there, so the label is the first k whose
+        // exp(x_k - m) / s equals the maximum probability, not the largest logit
+        if (am > 0) {
+            for (int k = 0; k < am; ++k)
+                if (expf(x[(size_t)k * HW] - m) / s == p) { am = k; break; }
+        }
         prob[idx] = p;
         label[idx] = am;
         mine += (p >= thr) ? 1u : 0u;

@@ -21,7 +21,7 @@ from . import ops
 
 
 class StagedExtractor:
-    def __init__(self, ldm, batched_inputs, unet_streams=3, **kwargs):
+    def __init__(self, ldm, batched_inputs, unet_streams=3, streams=None, **kwargs):
         assert unet_streams >= 1
         self.ldm = ldm
         self.k = int(unet_streams)
@@ -32,8 +32,12 @@ class StagedExtractor:
             warnings.warn(f"StagedExtractor: {self.k + 1} streams on GPU_MAX_HW_QUEUES={q} hardware queues -- streams will "
                           "share queues and serialise; export GPU_MAX_HW_QUEUES>=%d before the process starts" % (self.k + 1))
         dev = batched_inputs['img'].device
-        self.s_enc = torch.cuda.Stream(device=dev)
-        self.s_unet = [torch.cuda.Stream(device=dev) for _ in range(self.k)]
+        if streams is not None:       # reuse another (idle) pipeline's streams: they already sit on pipes of their own
+            assert len(streams) == self.k + 1
+            self.s_enc, self.s_unet = streams[0], list(streams[1:])
+        else:
+            self.s_enc = torch.cuda.Stream(device=dev)
+            self.s_unet = [torch.cuda.Stream(device=dev) for _ in range(self.k)]
         self.enc_graphs, self.unet_graphs, self.slots, self.outs = [], [], [], []
         cur = torch.cuda.current_stream(dev)
         with torch.no_grad():

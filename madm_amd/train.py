@@ -23,7 +23,7 @@ class MadmTrainer:
 
     def __init__(self, model, lr, weight_decay, grad_clip=None, unet_lr=None, betas=(0.9, 0.999), eps=1e-8, dist=None,
                  amp=True, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
-                 lr_multiplier=None):
+                 lr_multiplier=None, exchange="allreduce", wire_dtype=None):
         self.model = model
         table = optim.default_optimizer_params(model, lr, weight_decay, weight_decay_norm=0.0, weight_decay_bias=0.0,
                                                unet_lr=unet_lr)
@@ -44,7 +44,7 @@ class MadmTrainer:
         self.opt = optim.TableAdamW(table, betas=betas, eps=eps)
         self.grad_clip = grad_clip
         self.dist = dist
-        self.reducer = GradBucketReducer(self.opt.flat.grad, dist)
+        self.reducer = GradBucketReducer(self.opt.flat.grad, dist, mode=exchange, wire_dtype=wire_dtype)
         self._index = {id(p): i for i, p in enumerate(self.opt.flat.params)}
         self._final = [False] * len(self.opt.flat.params)
         self._ptr = len(self._final) - 1

@@ -4,6 +4,7 @@ assumes.  Runs on CPU."""
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.multiprocessing as mp
 
@@ -71,12 +72,17 @@ def _grad_worker(rank, world, port, q):
     from madm_amd import dist as mdist
     d = mdist.init(backend="gloo")
     n = 1000
-    g = torch.arange(n, dtype=torch.float32) * (rank + 1)          # rank r holds (r + 1) * [0, 1, 2, ...]
-    red = mdist.GradBucketReducer(g, d, bucket_numel=96)           # ragged: 1000 = 10 * 96 + 40
-    red.reduce_tail(700)                                           # the explicit backward fills the buffer back to front
-    red.reduce_tail(250)
-    red.finish()
-    q.put((rank, g.clone()))
+    out = {}
+    # fp32 all-reduce (DDP's path), reduce-scatter + all-gather (the mesh-friendly form), and both with a 16-bit wire
+    for tag, kw in (("allreduce", {}), ("rs_ag", dict(mode="rs_ag")), ("bf16", dict(wire_dtype=torch.bfloat16)),
+                    ("rs_ag_f16", dict(mode="rs_ag", wire_dtype=torch.float16))):
+        g = torch.arange(n, dtype=torch.float32) * (rank + 1)      # rank r holds (r + 1) * [0, 1, 2, ...]
+        red = mdist.GradBucketReducer(g, d, bucket_numel=97, **kw)  # ragged AND odd: 1000 = 10 * 97 + 30, tails not / world
+        red.reduce_tail(701)                                       # the explicit backward fills the buffer back to front
+        red.reduce_tail(250)
+        red.finish()
+        out[tag] = g.numpy().copy()
+    q.put((rank, out))
     d.barrier()
     d.destroy_process_group()
 
@@ -96,8 +102,16 @@ def test_gradient_all_reduce_mean_two_rank_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     want = torch.arange(1000, dtype=torch.float32) * 1.5           # mean of 1x and 2x
-    for _, g in res:
-        assert torch.equal(g, want)
+    for _, out in res:
+        assert torch.equal(torch.from_numpy(out["allreduce"]), want)          # fp32 modes: exact, every element once
+        assert torch.equal(torch.from_numpy(out["rs_ag"]), want)
+        # 16-bit wire (DDP's fp16 / bf16 compress hooks): each addend (g / world) and the sum are rounded to the wire type ->
+        # relative error <= 2^-8 (bf16: 8 significand bits) / 2^-11 (f16) per rounding, two roundings; stated tolerance 1.5x that
+        for tag, eps in (("bf16", 2.0 ** -8), ("rs_ag_f16", 2.0 ** -11)):
+            got = torch.from_numpy(out[tag])
+            assert ((got - want).abs() <= 1.5 * 2 * eps * want.abs()).all(), tag
+            assert not torch.equal(got, want)                                  # (it IS lossy: 1.5 * 999 is not a bf16 / f16 number)
+    assert all(np.array_equal(res[0][1][k], res[1][1][k]) for k in res[0][1])  # the ranks agree bit for bit in every mode
 
 
 def test_gradient_reducer_is_a_no_op_for_one_rank():

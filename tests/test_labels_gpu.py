@@ -63,6 +63,17 @@ def test_pseudo_labels(cuda):
     assert torch.equal(l2.cpu(), torch.full((1, 4, 4), 1, dtype=torch.int64))
     p0, l0, _ = L.pseudo_labels(x, (4, 4), 0.9)
     assert torch.equal(l0, l2.cpu())
+    # near-ties: the reference's argmax runs over the f32 softmax VALUES (mtmadise.py:340-341) -- a later channel whose
+    # logit is larger by an ulp rounds to the same probability and loses against the earlier one; the kernel follows the
+    # probabilities, not the logits (ADVICE r1 / VERDICT r2: "logits-vs-softmax argmax")
+    y = torch.zeros((1, 6, 4, 4))
+    y[0, 2] = 0.1                                                           # (ulp(0.1) = 7.5e-9 < the 6e-8 spacing of f32
+    y[0, 4] = float(np.nextafter(np.float32(0.1), np.float32(1.0)))         # below 1: exp(-ulp) rounds to exactly 1)
+    y[0, 5, 0, 0] = 0.1 + 1e-3                                              # a clear winner on one pixel
+    pr, lr_, _ = L.pseudo_labels(y, (4, 4), 0.9)
+    assert lr_[0, 1, 1].item() == 2 and lr_[0, 0, 0].item() == 5 and y[0, 4, 1, 1] > y[0, 2, 1, 1]
+    pg, lg, _ = labels.pseudo_labels(y.cuda(), (4, 4), 0.9)
+    assert torch.equal(lg.cpu(), lr_) and (pg.cpu() - pr).abs().max() < 2e-6
 
 
 def test_class_mix_matches_reference_fixture(cuda):

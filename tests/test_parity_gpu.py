@@ -15,6 +15,12 @@ pytestmark = pytest.mark.gpu
 F32_TOL = 1e-3
 BF16_L2_TOL = 4e-2
 F16_L2_TOL = 8e-3     # fp16 storage (10 mantissa bits): the reference's own autocast arithmetic (engine/train_loop.py:277)
+# Per-tensor gates of the golden comparisons = 2x the worst value observed on MI355X over the four cases
+# (profiles/round2_precision_f16_bf16.txt; f32: max-relative 2.6e-6 .. 6.0e-6, gate 20x that -- north_star's bound is 1e-3):
+#            latents   sample    taps
+GOLD_TOL = {torch.float32: dict(latents=1e-4, sample=1e-4, tap=1e-4),          # max |a - b| / max |b|
+            torch.float16: dict(latents=4.0e-3, sample=4.5e-3, tap=5.0e-3),    # relative L2 (observed <= 1.97 / 2.22 / 2.52e-3)
+            torch.bfloat16: dict(latents=2.8e-2, sample=4.0e-2, tap=3.8e-2)}   # relative L2 (observed <= 1.37 / 1.95 / 1.89e-2)
 
 
 class _LoraConfig:
@@ -55,7 +61,8 @@ def _compare(name, got, gold, dtype):
     for key, a, b in pairs:
         e, l2 = rel_err(a, b)
         report.append(f"{key}: max {e:.2e} l2 {l2:.2e}")
-        ok &= (e < F32_TOL) if dtype == torch.float32 else (l2 < (F16_L2_TOL if dtype == torch.float16 else BF16_L2_TOL))
+        tol = GOLD_TOL[dtype]["tap" if key.startswith("tap") else key]
+        ok &= (e < tol) if dtype == torch.float32 else (l2 < tol)
     print(name, dtype, "; ".join(report))
     assert ok, f"{name} {dtype}: " + "; ".join(report)
 
