@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MADM_ABI_VERSION 1
+#define MADM_ABI_VERSION 2
 
 typedef enum {
     MADM_OK = 0,
@@ -123,6 +123,16 @@ typedef struct {
     int splitk;           /* >=1; >1 needs workspace (f32 [splitk][M][N]) */
     void* workspace;
     size_t workspace_bytes;
+    /* LayerNorm of the INPUT rows folded into a linear layer (ABI 2; diffusers BasicTransformerBlock norm1 -> attn1
+     * to_q/k/v, norm2 -> attn2.to_q, norm3 -> ff.net.0.proj, modeling/meta_arch/ldm_diffusers.py:454-616 runs them as
+     * nn.LayerNorm + nn.Linear): in1 holds the RAW rows x [M][C1]; w holds W' = W * gamma (column k scaled by gamma[k]);
+     * ln_colsum f32 [N] = sum_k W'[n][k] (of the ROUNDED W'); bias = W beta + b.  The kernel takes sum x / sum x^2 of
+     * every row from the operand fragments it reads anyway and stores
+     *     out[m][n] = rstd_m * (sum_k x[m][k] W'[n][k] - mean_m * ln_colsum[n]) + bias[n]    (then the epilogue)
+     * == Linear(LayerNorm(x)); no separate normalisation pass, no re-read.  NULL = off.  Needs KH = KW = 1, one source,
+     * splitk == 1 (every workgroup walks whole rows), no fused GroupNorm. */
+    const float* ln_colsum;
+    float ln_eps;
 } madm_conv2d_args;
 
 size_t madm_conv2d_workspace_bytes(const madm_conv2d_args* a);

@@ -54,6 +54,7 @@ class Conv2dArgs(ctypes.Structure):
         ("splitk", c_int),
         ("workspace", c_void_p),
         ("workspace_bytes", c_size_t),
+        ("ln_colsum", c_void_p), ("ln_eps", ctypes.c_float),
     ]
 
 

@@ -27,7 +27,7 @@ __device__ unsigned long long g_reg_stamps[64];
 // no wave reads any more (the caller has passed a barrier since the last MFMA operand read).
 template <typename T, int BM, int BN>
 __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0,
-                                                    int z, float* red) {
+                                                    int z, float* red, float (&lns)[BM / 32], float (&lnq)[BM / 32]) {
     constexpr int MI = BM / 32, NI = BN / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -42,6 +42,32 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc
 #pragma unroll
     for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     if (p.splitk == 1) epilogue_consts<NI>(p, nb, one_image ? img0 : -1, add);
+    if (p.ln_cs) {
+        // folded LayerNorm: the lane's partial row sums cover the chunks it read (lane >> 4, + 4 per half tile); the four
+        // lanes that share lane & 15 hold the rest of the row
+        f32x4 csv[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            csv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (nb + 16 * j < p.N) {
+                const float4 c = *reinterpret_cast<const float4*>(p.ln_cs + nb + 16 * j);
+                csv[j] = f32x4{c.x, c.y, c.z, c.w};
+            }
+        }
+        const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float sx = lns[i], sq = lnq[i];
+            sx += __shfl_xor(sx, 16); sq += __shfl_xor(sq, 16);
+            sx += __shfl_xor(sx, 32); sq += __shfl_xor(sq, 32);
+            const float mean = sx * inv_k;
+            float var = sq * inv_k - mean * mean;
+            var = var < 0.f ? 0.f : var;
+            const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = (acc[i][j] - mean * csv[j]) * rstd;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + frow;
@@ -205,6 +231,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float lns[MI], lnq[MI];   // folded LayerNorm: partial row sums of the lane's A-fragment rows
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { lns[i] = 0.f; lnq[i] = 0.f; }
+    const bool ln_on = p.ln_cs != nullptr;   // block-uniform
+
     // Pipeline: LDS buffer ((t - kt0) & 1) holds tile t; register stage (t + j) % NST holds tile t + j for
     // j = 1 .. NST-1; the loads of tile t + NST are issued before the MFMAs of tile t into the stage that held
     // tile t, and get NST MFMA phases to land (small grids have no co-resident block to hide the latency).
@@ -229,6 +260,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
                 wf[j] = sB[(wn * (BN / 2) + j * 16 + frow) * 8 + c];                                \
             _Pragma("unroll") for (int i = 0; i < MI; ++i)                                          \
                 _Pragma("unroll") for (int j = 0; j < NI; ++j) mma16<T>(wf[j], af[i], acc[i][j]);   \
+            if (ln_on) {                                                                            \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i) ln_accum<T>(af[i], lns[i], lnq[i]);  \
+            }                                                                                       \
         }                                                                                           \
     }
     REG_BSTAMP(2);
@@ -252,7 +286,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
 #undef IGEMM_STORE_TILE
 
     REG_BSTAMP(3);
-    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(smem));
+    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(smem), lns, lnq);
     REG_BSTAMP(4);
 #ifdef GLDS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -395,6 +429,11 @@ __global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_k
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float lns[MI], lnq[MI];   // folded LayerNorm: partial row sums of the lane's A-fragment rows
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { lns[i] = 0.f; lnq[i] = 0.f; }
+    const bool ln_on = p.ln_cs != nullptr;   // block-uniform
+
     GLDS_BSTAMP(1);
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
@@ -457,6 +496,12 @@ __global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_k
             _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
                 _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
                     mma16<T>(__builtin_bit_cast(uint4, wf[1][j]), __builtin_bit_cast(uint4, af[1][i]), acc[i][j]); \
+            if (ln_on) {                                                                                         \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                 \
+                    ln_accum<T>(__builtin_bit_cast(uint4, af[0][i]), lns[i], lnq[i]);                            \
+                    ln_accum<T>(__builtin_bit_cast(uint4, af[1][i]), lns[i], lnq[i]);                            \
+                }                                                                                                \
+            }                                                                                                    \
         }                                                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
         GLDS_STAMP(t, 3);                                                                                        \
@@ -473,7 +518,7 @@ __global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_k
 #undef GLDS_LOAD_TILE
     GLDS_BSTAMP(3);
     __syncthreads();   // every wave is done with the last tile: the LDS becomes the statistics scratch
-    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(gsmem));
+    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(gsmem), lns, lnq);
     GLDS_BSTAMP(4);
 #endif
 }
@@ -674,6 +719,14 @@ int fill_params(const madm_conv2d_args* a, IgemmP& p) {
     p.out = (char*)a->out; p.ws = (float*)a->workspace; p.stats = a->stats;
     p.gn_sums1 = nullptr; p.gn_sums2 = nullptr; p.gn_gamma = nullptr; p.gn_beta = nullptr;
     p.gn_G = 0; p.gn_eps = 0.f; p.gn_magic = 0; p.act = 0;
+    p.ln_cs = a->ln_colsum; p.ln_eps = a->ln_eps;
+    if (a->ln_colsum) {
+        MADM_REQUIRE(a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad_t == 0 && a->pad_l == 0 && !a->upsample &&
+                     a->C2 == 0 && a->OH == a->IH && a->OW == a->IW,
+                     "conv2d: the folded LayerNorm needs a linear layer / 1x1 conv over ONE source (K = C1)");
+        MADM_REQUIRE(!a->gn_sums1 && a->ln_eps > 0.f && a->splitk == 1,
+                     "conv2d: folded LayerNorm: no fused GroupNorm, eps > 0, splitk == 1 (every block must see whole rows)");
+    }
     MADM_REQUIRE(!a->stats || a->epilogue != MADM_EPI_GEGLU, "conv2d: fused statistics cannot follow GEGLU");
     p.C1 = a->C1; p.C2 = a->C2; p.Ctot = a->C1 + a->C2;
     p.B = a->B; p.IH = a->IH; p.IW = a->IW; p.OH = a->OH; p.OW = a->OW;

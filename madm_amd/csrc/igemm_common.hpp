@@ -15,7 +15,41 @@ struct IgemmP {
     // sums of the (one or two) sources: group g = c / cpg == __umulhi(c, gn_magic)
     const double* gn_sums1; const double* gn_sums2; const float* gn_gamma; const float* gn_beta;
     int gn_G; float gn_eps; unsigned gn_magic; int act;
+    // linear layers only: LayerNorm of the INPUT rows folded into the GEMM (madm_conv2d_args.ln_colsum): the kernel reads
+    // RAW rows x, w holds gamma-scaled weights W', and  out = rstd_m (x W'^T - mean_m colsum(W')) + bias  with the row
+    // sums taken from the A fragments the waves read anyway (K = C: every block walks whole rows)
+    const float* ln_cs; float ln_eps;
 };
+
+// Row sums of one 16-byte A-fragment chunk (the lane's row, 8 / 4 consecutive k): s += sum x, q += sum x^2 (f32).
+template <typename T> __device__ __forceinline__ void ln_accum(const uint4& a, float& s, float& q);
+template <> __device__ __forceinline__ void ln_accum<float>(const uint4& a, float& s, float& q) {
+    const float4 v = __builtin_bit_cast(float4, a);
+    s += (v.x + v.y) + (v.z + v.w);
+    q = fmaf(v.x, v.x, q); q = fmaf(v.y, v.y, q); q = fmaf(v.z, v.z, q); q = fmaf(v.w, v.w, q);
+}
+template <> __device__ __forceinline__ void ln_accum<f16_t>(const uint4& a, float& s, float& q) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const h2 v = __builtin_bit_cast(h2, w[i]);
+        s = __builtin_amdgcn_fdot2(v, one, s, false);       // v_dot2c_f32_f16: exact products, f32 accumulation
+        q = __builtin_amdgcn_fdot2(v, v, q, false);
+    }
+}
+template <> __device__ __forceinline__ void ln_accum<bf16_t>(const uint4& a, float& s, float& q) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 one = {(__bf16)1.0f, (__bf16)1.0f};
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const b2 v = __builtin_bit_cast(b2, w[i]);
+        s = __builtin_amdgcn_fdot2_f32_bf16(v, one, s, false);
+        q = __builtin_amdgcn_fdot2_f32_bf16(v, v, q, false);
+    }
+}
 
 // GroupNorm finalize inside the consumer: gstat[g] = {mean_g, rstd_g} of image b from the per-channel sums.
 // All 256 threads: 8 lanes per group, every lane's loads in flight together, xor-shuffle reduction (f64 like

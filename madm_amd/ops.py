@@ -60,6 +60,9 @@ EXP_NO_STATS = bool(int(__import__('os').environ.get('MADM_EXP_NO_STATS', '0')))
 FORCE_SPLITK = None   # tools/tune_insitu.py: split-K factor forced on every small-M launch
 if os.environ.get("MADM_EXP_SPLITK"):   # experiment: e.g. 1 = no split-K anywhere (does the staged pipeline still want it?)
     FORCE_SPLITK = int(os.environ["MADM_EXP_SPLITK"])
+# timing experiments only (results become garbage): launches of the named classes are skipped -- "layernorm", "gn_apply",
+# "attention", "softmax", or tile codes of madm_conv2d_pick_tile ("tile7", ...): what would the step cost without them?
+EXP_SKIP = set(filter(None, os.environ.get("MADM_EXP_SKIP", "").split(",")))
 FUSE_GN = True   # fold GroupNorm(+SiLU) into eligible 3x3 convs (debug switch)
 HALO_MIN_W = int(__import__("os").environ.get("MADM_HALO_MIN_W", "8"))   # mirrors halo_min_width() of igemm.hip
 import os as _os
@@ -121,7 +124,7 @@ def _workspace(nbytes, device):
 
 def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
            upsample=False, bias=None, rowvec=None, residual=None, epilogue=EPI_NONE, out=None,
-           splitk=None, alg_nk=None, stats=None, gn=None, out_f32=False):
+           splitk=None, alg_nk=None, stats=None, gn=None, out_f32=False, ln=None):
     """Implicit-GEMM conv / linear.  x1: [B*IH*IW, C1] dense; x2 optional second source (concat);
     w: packed [N, KH*KW*(C1+C2)]; returns out [B*OH*OW, N] (N/2 columns for GEGLU)."""
     _need_cuda(x1, w, x2, bias, rowvec, residual, out)
@@ -182,6 +185,12 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         a.gn_sums2 = sums[1].data_ptr() if len(sums) > 1 else None
         a.gn_gamma, a.gn_beta = gamma.data_ptr(), beta.data_ptr()
         a.gn_groups, a.gn_eps, a.gn_act = int(groups), float(eps), _act_code(act=act)
+    if ln is not None:   # (colsum f32 [N] of the gamma-scaled packed weight, eps): LayerNorm of the input rows folded in
+        cs, eps = ln
+        _need_cuda(cs)
+        assert cs.dtype == torch.float32 and cs.is_contiguous() and cs.numel() == N and x2 is None and KH == 1 and gn is None
+        a.ln_colsum, a.ln_eps = cs.data_ptr(), float(eps)
+        splitk = 1       # every workgroup must walk whole rows (the row sums come from its own A fragments)
     a.splitk = 1
     if FORCE_SPLITK is not None and splitk is None:
         nk = KH * KW * (C1 + C2) // k_tile(x1.dtype)
@@ -195,6 +204,8 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         ws = _workspace(nbytes, x1.device)
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
+    if EXP_SKIP and ("tile%d" % lib.madm_conv2d_pick_tile(ctypes.byref(a))) in EXP_SKIP:
+        return out
     if PROFILE is None:
         check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     else:
@@ -217,13 +228,13 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
 
 
 def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=None, splitk=None, alg_nk=None,
-           stats=None, B=1, out_f32=False):
+           stats=None, B=1, out_f32=False, ln=None):
     """out = x @ w.T (+bias) (+residual); x: [M, K] dense, w: [N, K(+K2)].  ``stats`` ([B, N, 2]) asks for
     the fused GroupNorm statistics of the output, the M rows being B images of M/B tokens."""
     M = x.shape[0]
     assert M % B == 0
     return conv2d(x, w, B, M // B, 1, N=w.shape[0], x2=x2, bias=bias, residual=residual,
-                  epilogue=epilogue, out=out, splitk=splitk, alg_nk=alg_nk, stats=stats, out_f32=out_f32)
+                  epilogue=epilogue, out=out, splitk=splitk, alg_nk=alg_nk, stats=stats, out_f32=out_f32, ln=ln)
 
 
 def conv2d_wgrad(x1, dout, B, IH, IW, *, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
@@ -449,6 +460,8 @@ def groupnorm(xs, B, HW, G, gamma, beta, eps, silu=False, stats=None, act=None, 
     off = 0
     for x in xs:
         assert x.is_contiguous()
+        if "gn_apply" in EXP_SKIP:
+            break
         check(lib.madm_groupnorm_apply(dtype_code(x), x.data_ptr(), out.data_ptr(), out.stride(0), B, HW, x.shape[1],
                                        off, Ctot, G, stats[0].data_ptr(), C1, s2, gamma.data_ptr(), beta.data_ptr(),
                                        float(eps), _act_code(silu, act), _ptr(residual),
@@ -531,6 +544,8 @@ def layernorm(x, gamma, beta, eps, out=None):
     assert x.is_contiguous() and x.dim() == 2
     if out is None:
         out = torch.empty_like(x)
+    if "layernorm" in EXP_SKIP:
+        return out
     check(lib.madm_layernorm_fwd(dtype_code(x), x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
                                  gamma.data_ptr(), beta.data_ptr(), float(eps), _stream()),
           "madm_layernorm_fwd")
@@ -551,6 +566,8 @@ def attention(q, k, v, B, H, Lq, Lk, D, scale, out=None):
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.B, a.H, a.Lq, a.Lk, a.D = B, H, Lq, Lk, D
     a.scale = float(scale)
+    if "attention" in EXP_SKIP:
+        return out
     with _Prof(f"attn_d{D}" + _SUFFIX[q.dtype], 4.0 * B * H * Lq * Lk * D,
                f"B{B} H{H} Lq{Lq} Lk{Lk}"):
         check(lib.madm_attention_fwd(ctypes.byref(a), _stream()), "madm_attention_fwd")

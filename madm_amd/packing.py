@@ -67,3 +67,19 @@ def pack_geglu_weight(w, b, dtype, ktile):
     wi = torch.stack([w[:half], w[half:]], dim=1).reshape(N, K)
     bi = torch.stack([b[:half], b[half:]], dim=1).reshape(N)
     return pack_linear_weight(wi, dtype, ktile), bi.float().contiguous()
+
+
+def fold_layernorm(w, b, gamma, beta, dtype, ktile):
+    """LayerNorm folded into the Linear that consumes it (madm_conv2d_args.ln_colsum):  Linear(LN(x)) =
+    rstd (x W'^T - mean colsum(W')) + (W beta + b)  with  W' = W * gamma  (column k scaled by gamma[k]).
+    w [N, K] f32 (rows already in the kernel's order, e.g. GEGLU-interleaved), b [N] f32 or None ->
+    (packed W' [N, pad(K)] of ``dtype``, bias' f32 [N], colsum f32 [N] of the ROUNDED W' so that the mean correction
+    cancels exactly what the MFMAs accumulate)."""
+    N, K = w.shape
+    assert K % ktile == 0, "the folded LayerNorm normalises over K = C: no channel padding"
+    wp = (w.double() * gamma.double()[None, :])
+    bias = (w.double() @ beta.double())
+    if b is not None:
+        bias = bias + b.double()
+    wq = wp.float().to(dtype)
+    return wq.contiguous(), bias.float().contiguous(), wq.double().sum(dim=1).float().contiguous()

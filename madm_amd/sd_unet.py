@@ -9,6 +9,8 @@ is a K-concatenated side GEMM.
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,6 +19,9 @@ from .nn import Tok, Conv2d, Linear, GroupNorm, LayerNorm, Identity, _Packed
 from ._lib import EPI_GEGLU
 
 LORA_PAD = 64  # K-extension of a LoRA-augmented GEMM (>= sum of the fused ranks), one bf16 K-tile
+
+
+FOLD_LN = not bool(int(os.environ.get("MADM_NO_FOLD_LN", "0")))   # LayerNorm folded into its consumer GEMM (A/B switch)
 
 
 # ----------------------------------------------------------------------------- LoRA
@@ -112,7 +117,26 @@ class _FusedProj(_Packed):
             Wp = packing.pack_linear_weight(W, dtype, kt)
         return Wp, bias, A_packed
 
-    def forward(self, x, residual=None):
+    def has_active_lora(self):
+        return any(isinstance(l, LoraLinear) and l.active() for l in self._layers)
+
+    def _build_ln(self, dtype, norm):
+        bases = [_base(l) for l in self._layers]
+        W = torch.cat([b.weight.detach().float() for b in bases], 0)
+        bias = None
+        if any(b.bias is not None for b in bases):
+            bias = torch.cat([b.bias.detach().float() if b.bias is not None
+                              else torch.zeros(b.out_features, device=W.device) for b in bases])
+        return packing.fold_layernorm(W, bias, norm.weight.detach().float(), norm.bias.detach().float(), dtype,
+                                      ops.k_tile(dtype))
+
+    def forward(self, x, residual=None, ln=None):
+        """``ln``: a LayerNorm module -- ``x`` holds the RAW rows and the normalisation is folded into the GEMM
+        (packing.fold_layernorm; no LoRA adapter may be active: its skinny GEMM would need the normalised rows)."""
+        if ln is not None:
+            ver = self._versions() + (ln.weight._version, ln.bias._version, ln.weight.data_ptr())
+            Wp, bias, cs = self._cache_get((x.dtype, "ln"), lambda: self._build_ln(x.dtype, ln), ver=ver)
+            return ops.linear(x, Wp, bias=bias, residual=residual, ln=(cs, ln.eps))
         Wp, bias, A = self._cache_get((x.dtype,), lambda: self._build(x.dtype))
         if A is None:
             return ops.linear(x, Wp, bias=bias, residual=residual)
@@ -145,16 +169,17 @@ class Attention(nn.Module):
     def has_active_lora_kv(self):
         return any(isinstance(m, LoraLinear) and m.active() for m in (self.to_k, self.to_v))
 
-    def forward(self, x, B, L, ctx=None, Lk=None, residual=None, kv=None):
-        """x: [B*L, C] normalised tokens; ctx: [B*Lk, 768] for cross attention (or ``kv`` = the precomputed
+    def forward(self, x, B, L, ctx=None, Lk=None, residual=None, kv=None, ln=None):
+        """x: [B*L, C] normalised tokens (``ln``: a LayerNorm module -> x holds the RAW tokens and the norm is folded into
+        the projection that reads them); ctx: [B*Lk, 768] for cross attention (or ``kv`` = the precomputed
         [B*Lk, 2C] view of the UNet-wide batched K/V projection); returns to_out(attn) + residual."""
         C = self.heads * self.dim_head
         if not self.is_cross:
-            qkv = self._fused("_f_qkv", ("to_q", "to_k", "to_v"))(x)
+            qkv = self._fused("_f_qkv", ("to_q", "to_k", "to_v"))(x, ln=ln)
             q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
             Lk = L
         else:
-            q = self._fused("_f_q", ("to_q",))(x)
+            q = self._fused("_f_q", ("to_q",))(x, ln=ln)
             if kv is None:
                 kv = self._fused("_f_kv", ("to_k", "to_v"))(ctx)
             k, v = kv[:, :C], kv[:, C:]
@@ -179,7 +204,20 @@ class GEGLU(_Packed):
     def _versions(self):
         return tuple((p._version, p.data_ptr()) for p in self.proj.parameters())
 
-    def forward(self, x):
+    def forward(self, x, ln=None):
+        if ln is not None:     # raw rows in, LayerNorm folded into the projection (packing.fold_layernorm)
+            def build_ln():
+                w = self.proj.weight.detach().float()
+                b = self.proj.bias.detach().float()
+                N, half = w.shape[0], w.shape[0] // 2
+                wi = torch.stack([w[:half], w[half:]], dim=1).reshape(N, w.shape[1])     # (value_j, gate_j) rows
+                bi = torch.stack([b[:half], b[half:]], dim=1).reshape(N)
+                return packing.fold_layernorm(wi, bi, ln.weight.detach().float(), ln.bias.detach().float(), x.dtype,
+                                              ops.k_tile(x.dtype))
+            ver = self._versions() + (ln.weight._version, ln.bias._version, ln.weight.data_ptr())
+            w, b, cs = self._cache_get((x.dtype, "ln"), build_ln, ver=ver)
+            return ops.linear(x, w, bias=b, epilogue=EPI_GEGLU, ln=(cs, ln.eps))
+
         def build():
             w, b = packing.pack_geglu_weight(self.proj.weight.detach().float(), self.proj.bias.detach().float(),
                                              x.dtype, ops.k_tile(x.dtype))
@@ -193,8 +231,8 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), Identity(), Linear(dim * mult, dim)])
 
-    def forward(self, x, residual=None):
-        return self.net[2](self.net[0](x), residual=residual)
+    def forward(self, x, residual=None, ln=None):
+        return self.net[2](self.net[0](x, ln=ln), residual=residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -208,10 +246,17 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, h, B, L, ctx, Lk):
-        h = self.attn1(self.norm1(h), B, L, residual=h)
-        kv = ctx.kv.get(id(self.attn2)) if isinstance(ctx, CtxKV) else None
-        h = self.attn2(self.norm2(h), B, L, ctx=ctx.t if isinstance(ctx, CtxKV) else ctx, Lk=Lk, residual=h, kv=kv)
-        h = self.ff(self.norm3(h), residual=h)
+        """The three LayerNorms are folded into the GEMMs that consume them (QKV, cross-attention Q, GEGLU projection:
+        FOLD_LN) -- 48 launches per UNet forward less; with an active LoRA adapter on a consuming projection the norm runs
+        as its own pass (the adapter's skinny GEMM reads the normalised rows)."""
+        a1, a2 = self.attn1, self.attn2
+        f1 = FOLD_LN and not a1._fused("_f_qkv", ("to_q", "to_k", "to_v")).has_active_lora()
+        h = a1(h if f1 else self.norm1(h), B, L, residual=h, ln=self.norm1 if f1 else None)
+        kv = ctx.kv.get(id(a2)) if isinstance(ctx, CtxKV) else None
+        f2 = FOLD_LN and not a2._fused("_f_q", ("to_q",)).has_active_lora()
+        h = a2(h if f2 else self.norm2(h), B, L, ctx=ctx.t if isinstance(ctx, CtxKV) else ctx, Lk=Lk, residual=h, kv=kv,
+               ln=self.norm2 if f2 else None)
+        h = self.ff(h if FOLD_LN else self.norm3(h), residual=h, ln=self.norm3 if FOLD_LN else None)
         return h
 
 

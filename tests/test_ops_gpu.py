@@ -232,6 +232,62 @@ def test_linear_geglu(cuda, dtype):
     assert e < TOL[dtype], f"geglu: {e:.3e} {l2:.3e}"
 
 
+LN_FOLD_CASES = [
+    # name, M, C, N, tile (0 = tuned / heuristic), geglu, residual
+    ("qkv_64sq", 300, 320, 960, 0, False, False),
+    ("q_glds64", 512, 1280, 1280, 7, False, True),
+    ("q_glds64s_ragged", 130, 640, 640, 11, False, True),
+    ("geglu_glds128", 256, 320, 2560, 8, True, False),
+    ("geglu_reg128x64", 200, 640, 1024, 2, True, False),
+    ("reg128x128", 256, 320, 256, 1, False, False),
+    ("reg64x64", 96, 64, 128, 3, False, True),
+    ("reg64x64d", 70, 128, 64, 6, False, False),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", LN_FOLD_CASES, ids=[c[0] for c in LN_FOLD_CASES])
+def test_linear_with_folded_layernorm(cuda, dtype, case):
+    """Linear(LayerNorm(x)) as ONE GEMM (madm_conv2d_args.ln_colsum, packing.fold_layernorm): the three norms of diffusers'
+    BasicTransformerBlock in front of to_q/k/v, attn2.to_q and the GEGLU projection.  Rows with a large mean / spread test
+    the cancellation in  rstd (x W'^T - mean colsum W');  reference = torch LayerNorm + linear in f32 on the rounded x."""
+    from madm_amd import ops, packing
+    from madm_amd._lib import lib
+    name, M, C, N, tile, geglu, with_res = case
+    kt = ops.k_tile(dtype)
+    x = _gen((M, C), 1) * (0.5 + 2.0 * torch.rand((M, 1), generator=torch.Generator().manual_seed(7))) \
+        + 3.0 * _gen((M, 1), 8)                                            # per-row scale and offset
+    x = _q(x, dtype)
+    gamma, beta = 1.0 + 0.3 * _gen((C,), 2), 0.2 * _gen((C,), 3)
+    w = _gen((N, C), 4) / math.sqrt(C)
+    b = _gen((N,), 5)
+    ref = F.linear(F.layer_norm(x, (C,), gamma, beta, 1e-5), w, b)
+    if geglu:
+        val, gate = ref.chunk(2, dim=-1)
+        ref = val * F.gelu(gate)
+        half = N // 2
+        wk = torch.stack([w[:half], w[half:]], dim=1).reshape(N, C)
+        bk = torch.stack([b[:half], b[half:]], dim=1).reshape(N)
+    else:
+        wk, bk = w, b
+    res = _q(_gen((M, N), 6), dtype) if with_res else None
+    if with_res:
+        ref = ref + res
+    wp, bp, cs = packing.fold_layernorm(wk, bk, gamma, beta, dtype, kt)
+    lib.madm_debug_set_conv_tile(tile)
+    try:
+        out = ops.linear(x.to(dtype).cuda(), wp.cuda(), bias=bp.cuda(), ln=(cs.cuda(), 1e-5),
+                         epilogue=ops.EPI_GEGLU if geglu else ops.EPI_NONE,
+                         residual=None if res is None else res.to(dtype).cuda())
+        torch.cuda.synchronize()
+    finally:
+        lib.madm_debug_set_conv_tile(0)
+    e, l2 = rel_err(out.float().cpu(), ref)
+    # f16 / bf16: W' = W * gamma is rounded once more than the unfused path's weights; same order as the GEMM's own error
+    tol = {torch.float32: 3e-5, torch.bfloat16: 1.5e-2, torch.float16: 2.5e-3}[dtype]
+    assert e < tol, f"{name}: max rel err {e:.3e} l2 {l2:.3e}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 64, 8, 8), (2, 320, 16, 16), (1, 128, 33, 17), (2, 1280, 2, 2)])
 @pytest.mark.parametrize("silu", [False, True])
