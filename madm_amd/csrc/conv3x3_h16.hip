@@ -560,7 +560,11 @@ namespace {
 template <typename T, int BN, bool FUSE, bool WIDE>
 int launch_h16_one(const IgemmP& p0, hipStream_t s) {
     IgemmP p = p0;
-    constexpr size_t lds = (size_t)((H16_PIX + 7) / 8) * 1024 + 2 * (size_t)BN * 128 + 32 * sizeof(float2);
+    constexpr size_t lds0 = (size_t)((H16_PIX + 7) / 8) * 1024 + 2 * (size_t)BN * 128 + 32 * sizeof(float2);
+    // experiment (MADM_EXP_H16_LDS=<bytes>): ask for more LDS than the kernel uses, e.g. 90112 -> ONE workgroup per CU, the
+    // rest of the CU stays free for the workgroups of kernels on other streams (staged pipeline)
+    static const size_t lds_exp = [] { const char* e = getenv("MADM_EXP_H16_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+    const size_t lds = lds_exp > lds0 ? lds_exp : lds0;
     auto kern = conv3x3_h16_kernel<T, BN, FUSE, WIDE>;
     // the attribute is per device: one bit per device id, set once (atomic: host threads may launch concurrently)
     static std::atomic<uint64_t> attr_set{0};
@@ -569,7 +573,7 @@ int launch_h16_one(const IgemmP& p0, hipStream_t s) {
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
+                                           (int)(lds > 64 * 1024 ? lds : 64 * 1024));
         if (e != hipSuccess) {
             madm_set_error("conv3x3 (16 x 16 patches): cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
             return MADM_ERR_LAUNCH;

@@ -55,11 +55,22 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc
             }
         }
         const float inv_k = 1.0f / (float)p.K;
+        // each of the two waves that own these rows (wn = 0 / 1) summed one K half of every tile: exchange through LDS
+        // (behind the statistics scratch: a fast wave may already write that while a slow one still reads here)
+        float2* lx = reinterpret_cast<float2*>(red + 4 * BN);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             float sx = lns[i], sq = lnq[i];
             sx += __shfl_xor(sx, 16); sq += __shfl_xor(sq, 16);
             sx += __shfl_xor(sx, 32); sq += __shfl_xor(sq, 32);
+            lns[i] = sx; lnq[i] = sq;
+            if (fg == 0) lx[(wave * MI + i) * 16 + frow] = make_float2(sx, sq);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const float2 o = lx[((wave ^ 1) * MI + i) * 16 + frow];
+            const float sx = lns[i] + o.x, sq = lnq[i] + o.y;
             const float mean = sx * inv_k;
             float var = sq * inv_k - mean * mean;
             var = var < 0.f ? 0.f : var;
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
                 wf[j] = sB[(wn * (BN / 2) + j * 16 + frow) * 8 + c];                                \
             _Pragma("unroll") for (int i = 0; i < MI; ++i)                                          \
                 _Pragma("unroll") for (int j = 0; j < NI; ++j) mma16<T>(wf[j], af[i], acc[i][j]);   \
-            if (ln_on) {                                                                            \
+            if (ln_on && kk == wn) {   /* the two waves that share these rows split the K halves */ \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i) ln_accum<T>(af[i], lns[i], lnq[i]);  \
             }                                                                                       \
         }                                                                                           \
@@ -496,10 +507,13 @@ __global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_k
             _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                       \
                 _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                   \
                     mma16<T>(__builtin_bit_cast(uint4, wf[1][j]), __builtin_bit_cast(uint4, af[1][i]), acc[i][j]); \
-            if (ln_on) {                                                                                         \
-                _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                 \
-                    ln_accum<T>(__builtin_bit_cast(uint4, af[0][i]), lns[i], lnq[i]);                            \
-                    ln_accum<T>(__builtin_bit_cast(uint4, af[1][i]), lns[i], lnq[i]);                            \
+            if (ln_on) {   /* the two waves that share these rows (wn = 0 / 1) split the K halves */              \
+                if (wn == 0) {                                                                                   \
+                    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                               \
+                        ln_accum<T>(__builtin_bit_cast(uint4, af[0][i]), lns[i], lnq[i]);                        \
+                } else {                                                                                         \
+                    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                               \
+                        ln_accum<T>(__builtin_bit_cast(uint4, af[1][i]), lns[i], lnq[i]);                        \
                 }                                                                                                \
             }                                                                                                    \
         }                                                                                                        \
@@ -602,6 +616,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
 
 int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
 inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8) || t == 11; }
+// tile 13 (igemm_apanel.hip): plain linear layer, one source, whole rows resident: no split-K, no residual / time row /
+// fused output statistics (its epilogue touches no global memory but the stores)
+inline bool apanel_eligible(const madm_conv2d_args* a) {
+    return a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad_t == 0 && a->pad_l == 0 && !a->upsample && a->C2 == 0 &&
+           a->OH == a->IH && a->OW == a->IW && a->splitk <= 1 && !a->stats && !a->residual && !a->rowvec && !a->gn_sums1 &&
+           igemm_apanel_bm(a->C1, (int)madm_esize(a->dtype)) > 0;
+}
 inline bool is_halo_tile(int t) { return t == 4 || t == 5 || t == 9 || t == 10 || t == 12; }
 
 // Launch configurations measured on MI355X by tools/tune_insitu.py for the layer shapes of the SD-v1-4
@@ -683,6 +704,14 @@ bool h16_upsample_eligible(const madm_conv2d_args* a) {
 }
 
 int pick_tile(const madm_conv2d_args* a) {
+    if (apanel_eligible(a)) {
+        if (g_tile_override == 13) return 13;
+        if (g_tile_override == 0) {
+            const int M = a->B * a->OH * a->OW;
+            if (const Tuned* t = find_tuned(a->dtype, M, a->N, a->C1, 1, 0))
+                if (t->tile == 13) return 13;
+        }
+    }
     if (h16_upsample_eligible(a) && (g_tile_override == 12 || (g_tile_override == 0 && h16_pays(a)))) return 12;
     const int t = pick_tile_raw(a);
     if (t == 12 && (a->OH < 16 || a->OW < 16)) return 9;   // the 16 x 16-patch kernel needs a map of at least one patch
@@ -793,6 +822,7 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
     int bm, bn;
     tile_dims(t, bm, bn);
     int rc;
+    if (t == 13) return launch_igemm_apanel<T>(p, s);
     if (is_halo_tile(t)) {
         rc = (t == 12) ? launch_conv3x3_h16<T>(p, bn, s)
                        : ((t >= 9) ? launch_conv3x3_halo_dma<T>(p, bn, s) : launch_conv3x3_halo<T>(p, bn, s));

@@ -248,5 +248,9 @@ __device__ __forceinline__ void stats_add_elementwise(const IgemmP& p, int m, in
 template <typename T> int launch_conv3x3_halo(const IgemmP& p, int bn, hipStream_t s);
 // conv3x3_dma.hip: the same with the weight tiles moved by LDS-DMA (three-slot ring, single halo buffer)
 template <typename T> int launch_conv3x3_halo_dma(const IgemmP& p, int bn, hipStream_t s);
+// igemm_apanel.hip (tile 13): linear layers with K = one channel row: resident A panel, streamed weight tiles, optional
+// LayerNorm in place; igemm_apanel_bm = rows per panel for this K (0: does not fit)
+template <typename T> int launch_igemm_apanel(const IgemmP& p, hipStream_t s);
+int igemm_apanel_bm(int K, int esize);
 // conv3x3_h16.hip: 16 x 16-pixel patches, 128 x 64 wave tiles, halo and weights by LDS-DMA (maps of at least 16 x 16)
 template <typename T> int launch_conv3x3_h16(const IgemmP& p, int bn, hipStream_t s);

@@ -55,7 +55,7 @@ PROFILE = None
 PROFILE_DIFF = False
 _TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64", 4: "conv3x3_halo_x128", 5: "conv3x3_halo_x64",
                6: "igemm_64x64d", 7: "igemm_glds_64x64", 8: "igemm_glds_128x64", 9: "conv3x3_halo_dma_x128",
-               10: "conv3x3_halo_dma_x64", 11: "igemm_glds_64x64s", 12: "conv3x3_h16_x128"}
+               10: "conv3x3_halo_dma_x64", 11: "igemm_glds_64x64s", 12: "conv3x3_h16_x128", 13: "igemm_apanel"}
 EXP_NO_STATS = bool(int(__import__('os').environ.get('MADM_EXP_NO_STATS', '0')))   # timing experiment only
 FORCE_SPLITK = None   # tools/tune_insitu.py: split-K factor forced on every small-M launch
 if os.environ.get("MADM_EXP_SPLITK"):   # experiment: e.g. 1 = no split-K anywhere (does the staged pipeline still want it?)
