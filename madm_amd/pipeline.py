@@ -36,8 +36,10 @@ class StagedExtractor:
             assert len(streams) == self.k + 1
             self.s_enc, self.s_unet = streams[0], list(streams[1:])
         else:
-            self.s_enc = torch.cuda.Stream(device=dev)
-            self.s_unet = [torch.cuda.Stream(device=dev) for _ in range(self.k)]
+            # experiment switch MADM_EXP_PRIO: "u" = UNet streams high priority, "e" = encoder stream high priority
+            prio = os.environ.get("MADM_EXP_PRIO", "")
+            self.s_enc = torch.cuda.Stream(device=dev, priority=-1 if prio == "e" else 0)
+            self.s_unet = [torch.cuda.Stream(device=dev, priority=-1 if prio == "u" else 0) for _ in range(self.k)]
         self.enc_graphs, self.unet_graphs, self.slots, self.outs = [], [], [], []
         cur = torch.cuda.current_stream(dev)
         with torch.no_grad():
