@@ -384,19 +384,8 @@ template <typename T, int NKB, int ND, int NW, int NS, int NQ = 1>
 int launch_attn(const AttnP& p, hipStream_t s) {
     using C = AttnCfg<T, NKB, ND, NW, NS, NQ>;
     auto kern = attn_kernel<T, NKB, ND, NW, NS, NQ>;
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        if (C::LDS_BYTES > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-            if (e != hipSuccess) {
-                madm_set_error("attention: cannot raise dynamic LDS to %zu: %s", (size_t)C::LDS_BYTES,
-                               hipGetErrorString(e));
-                return MADM_ERR_LAUNCH;
-            }
-        }
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(C::LDS_BYTES), attr_done, "attention")) return e;
     dim3 grid((unsigned)((p.Lq + C::BQ - 1) / C::BQ), (unsigned)(p.B * p.H));
     kern<<<grid, NW * 64, C::LDS_BYTES, s>>>(p);
     return madm_check_launch("attn_kernel");

@@ -271,19 +271,8 @@ template <typename T, int NKB, int ND, bool DKV>
 int launch_attn_bwd_one(const AttnBwdP& p, hipStream_t s) {
     using C = AttnBwdCfg<T, NKB>;
     auto kern = attn_bwd_kernel<T, NKB, ND, DKV>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (C::LDS_BYTES > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-            if (e != hipSuccess) {
-                madm_set_error("attention_bwd: cannot raise dynamic LDS to %zu: %s", (size_t)C::LDS_BYTES,
-                               hipGetErrorString(e));
-                return MADM_ERR_LAUNCH;
-            }
-        }
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(C::LDS_BYTES), attr_done, "attention_bwd")) return e;
     const int Lown = DKV ? p.Lk : p.Lq;
     dim3 grid((unsigned)((Lown + 63) / 64), (unsigned)(p.B * p.H));
     kern<<<grid, 256, C::LDS_BYTES, s>>>(p);

@@ -184,6 +184,25 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per device (bit per
+// device id in ``done``, atomic: host threads may launch concurrently).  ``done`` is a function-local static of the caller,
+// i.e. one per kernel instantiation.
+#include <atomic>
+inline int madm_raise_dynamic_lds(const void* kern, size_t lds, std::atomic<uint64_t>& done, const char* what) {
+    if (lds <= 64 * 1024) return MADM_OK;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return MADM_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        madm_set_error("%s: cannot raise dynamic LDS to %zu: %s", what, lds, hipGetErrorString(e));
+        return MADM_ERR_LAUNCH;
+    }
+    done.fetch_or(bit, std::memory_order_release);
+    return MADM_OK;
+}
+
 #define MADM_DISPATCH_DTYPE(dtype, ...)                          \
     do {                                                         \
         if ((dtype) == MADM_F32) {                               \

@@ -255,18 +255,8 @@ int launch_one(const IgemmP& p0, hipStream_t s) {
     IgemmP p = p0;
     constexpr size_t lds = (size_t)(2 * HPIX * 8 + 2 * BN * 8) * 16 + 32 * sizeof(float2);
     auto kern = conv3x3_halo_kernel<T, BN, FUSE, NWS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) {
-                madm_set_error("conv3x3: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
-                return MADM_ERR_LAUNCH;
-            }
-        }
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds), attr_done, "conv3x3")) return e;
     const int patchesX = (p.OW + TW - 1) / TW, patchesY = (p.OH + TH - 1) / TH;
     p.tilesN = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.B * patchesX * patchesY * p.tilesN), 1, (unsigned)p.splitk);

@@ -793,18 +793,8 @@ template <typename T, int BM, int BN, int NS, bool LIN>
 int launch_glds_v(const IgemmP& p, dim3 grid, hipStream_t s) {
     constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
     auto kern = igemm_glds_kernel<T, BM, BN, NS, LIN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) {
-                madm_set_error("igemm (LDS-DMA): cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e));
-                return MADM_ERR_LAUNCH;
-            }
-        }
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds), attr_done, "igemm (LDS-DMA)")) return e;
     kern<<<grid, 256, lds, s>>>(p);
     return MADM_OK;
 }

@@ -40,10 +40,9 @@ def main():
     from golden_util import TRAIN_CASE
     from madm_amd.train import MadmTrainer
     model = build_product_train(torch.float32, size=args.size)
-    with torch.no_grad():
+    with torch.no_grad():       # EVERY parameter, the frozen EMA teacher included: DDP's start-up broadcast covers them all
         for p in model.parameters():
-            if p.requires_grad:
-                p.add_(0.01 * rank)
+            p.add_(0.01 * rank)
     trainer = MadmTrainer(model, lr=1e-4, weight_decay=0.05, grad_clip=1.0, dist=dist, amp=False)
     trainer.reducer.bucket = 8 << 20            # the small model's buffer is ~3.5 GB: several buckets per backward
     g = torch.Generator().manual_seed(100 + rank)
@@ -62,8 +61,10 @@ def main():
               f"{trainer.last_overlap_frac}", flush=True)
     ok = True
     if dist is not None:
+        mine = {id(p) for p in trainer.opt.flat.params}
+        frozen = torch.cat([p.detach().flatten().float() for p in model.parameters() if id(p) not in mine])
         for name, t in (("parameters", trainer.opt.flat.flat), ("gradient", trainer.opt.flat.grad), ("exp_avg", trainer.opt.m),
-                        ("exp_avg_sq", trainer.opt.v)):
+                        ("exp_avg_sq", trainer.opt.v), ("frozen parameters (EMA teacher, VAE)", frozen)):
             ref = t.clone()
             dist.broadcast(ref, src=0)
             same = bool(torch.equal(ref, t))
