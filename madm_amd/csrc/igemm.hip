@@ -679,7 +679,8 @@ int pick_tile_raw(const madm_conv2d_args* a) {
             if (is_halo_tile(t->tile)) return t->tile;
         return halo_default;
     }
-    if (g_tile_override > 0 && (is_igemm_tile(g_tile_override) || halo_ok)) return g_tile_override;
+    if (g_tile_override > 0 && (is_igemm_tile(g_tile_override) || (is_halo_tile(g_tile_override) && halo_ok)))
+        return g_tile_override;   // (13 = the A-stationary kernel is handled by pick_tile; ineligible launches fall through)
     if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH, variant_of(a)))
         if (is_igemm_tile(t->tile) || halo_ok) return t->tile;
     if (halo_ok && M >= 2048) return halo_default;

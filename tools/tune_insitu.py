@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 TILE_OF = {"igemm_128x128": 1, "igemm_128x64": 2, "igemm_64x64": 3, "conv3x3_halo_x128": 4, "conv3x3_halo_x64": 5,
            "igemm_64x64d": 6, "igemm_glds_64x64": 7, "igemm_glds_128x64": 8,
-           "conv3x3_halo_dma_x128": 9, "conv3x3_halo_dma_x64": 10, "igemm_glds_64x64s": 11}
+           "conv3x3_halo_dma_x128": 9, "conv3x3_halo_dma_x64": 10, "igemm_glds_64x64s": 11, "conv3x3_h16_x128": 12,
+           "igemm_apanel": 13}
 
 
 def main():
@@ -28,14 +29,14 @@ def main():
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--workload", default="extract", choices=["extract", "eval"])
-    ap.add_argument("--tiles", type=int, nargs="*", default=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+    ap.add_argument("--tiles", type=int, nargs="*", default=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13])
     ap.add_argument("--splitk", type=int, nargs="*", default=[1, 2, 3, 4, 6, 8, 12, 16, 24])
     args = ap.parse_args()
     from madm_amd.ldm_rocm import LdmRocm
     from madm_amd import ops
     from madm_amd._lib import lib
     import bench
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     if args.workload == "eval":
         m = bench.build_eval_model(dtype, torch.device("cuda"))
         call = ([{"target_second_modality": 255.0 * torch.rand((3, args.size, args.size)).cuda()}],)
@@ -51,7 +52,7 @@ def main():
         m(*call)
         torch.cuda.synchronize()
         rec, ops.PROFILE = ops.PROFILE, None
-        return [(name, desc, e0.elapsed_time(e1) * 1e3) for name, _, e0, e1, desc, _, _ in rec if not name.startswith("attn")]
+        return [(name, desc, e0.elapsed_time(e1) * 1e3) for name, _, e0, e1, desc, _, _ in rec if not name.startswith(("attn", "stem_"))]
 
     # results[launch index][(tile, sk)] = [us...]; the launch sequence is identical in every forward
     base = profiled()
@@ -107,7 +108,7 @@ def main():
         print(f"{r[1]:42s} {r[2]:3d}  t{r[3][0]}/sk{r[3][1]:<3d} {r[4]:8.1f}   t{r[5][0]}/sk{r[5][1]:<3d} {r[6]:8.1f}")
     print("\n// ---- rows for igemm_tuned.inc: {dtype, M, N, K, KH, variant, tile, splitk}")
     seen = set()
-    dt = 1 if args.dtype == "bf16" else 0
+    dt = 0 if args.dtype == "f32" else 1      # one table serves both 16-bit types
     for r in sorted(rows, key=lambda r: r[7]):
         if r[7] in seen:      # same GEMM shape and variant reached through a different stride / source layout
             continue
