@@ -312,17 +312,19 @@ def test_train_step_matches_fixture(cuda, variant, dtype):
 
 
 def test_train_step_at_512_properties(cuda):
-    """The shipped crop size (2 x 3 x 512 x 512, BASELINE configs[3]) has no CPU fixture -- the oracle step takes minutes
+    """The shipped crop size (512 x 512, BASELINE configs[3]) has no CPU fixture -- the oracle step takes minutes
     there -- so the full-size step is held to properties: finite losses that agree between the f16 (bench) and f32 (strict)
     arithmetic, a gradient for EVERY trainable tensor, a finite total gradient norm within 5 % of the f32 run's, and the
     same pseudo labels on (almost) every pixel.  This is the only test that drives the 512 x 512 routing of the backward
     (decoder image -> s0 projection, head at full resolution, bilinear adjoints)."""
     import bench
-    data = bench.train_inputs(2, 512, torch.device("cuda"))
+    # one image: the f32 mode's head tensors (512^2 x 1024 channels x 4 B per image) reach the 2 GiB limit of the 32-bit
+    # buffer offsets at two (the f16 / bf16 modes, half the bytes, take the shipped batch of two: bench.py --workload train)
+    data = bench.train_inputs(1, 512, torch.device("cuda"))
     out = {}
     for dtype in (torch.float32, torch.float16):
         model = build_product_train(dtype, "train_depth", size=512, pseudo_threshold=0.25)
-        sc = train_dropout_scales(2)
+        sc = train_dropout_scales(1)
         model.sem_seg_head.dropout_scale_override = [sc[0], sc[1]]
         model.ema_sem_seg_head.dropout_scale_override = [sc[2]]
         random.seed(5)
