@@ -621,7 +621,9 @@ inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8) || t == 1
 inline bool apanel_eligible(const madm_conv2d_args* a) {
     return a->KH == 1 && a->KW == 1 && a->stride == 1 && a->pad_t == 0 && a->pad_l == 0 && !a->upsample && a->C2 == 0 &&
            a->OH == a->IH && a->OW == a->IW && a->splitk <= 1 && !a->stats && !a->residual && !a->rowvec && !a->gn_sums1 &&
-           igemm_apanel_bm(a->C1, (int)madm_esize(a->dtype)) > 0;
+           igemm_apanel_bm(a->C1, (int)madm_esize(a->dtype)) > 0 &&
+           // its stores go through a buffer descriptor with 32-bit offsets (0x80000000 = "drop this lane")
+           (size_t)a->B * a->OH * a->OW * (size_t)a->ldo * (a->out_f32 ? 4 : madm_esize(a->dtype)) < 0x80000000ull;
 }
 inline bool is_halo_tile(int t) { return t == 4 || t == 5 || t == 9 || t == 10 || t == 12; }
 
