@@ -272,7 +272,8 @@ def test_train_step_matches_fixture(cuda, variant, dtype):
     # bf16 3.8e-2 / 4.0e-1 / 7.1e-2 (16-bit storage of every activation AND gradient through ~250 layers)
     # (round 3: f32 probe errors of 3.0e-3 / 5.0e-3 on feature_projections.0.0.*.norm.bias in the depth / lora variants -- the
     # s0 path's ReLU kinks; which of them flip depends on the last bits of the forward, which the LayerNorm fold changed)
-    ntol, ptol = {torch.float32: (1e-3, 8e-3), torch.float16: (4e-2, 3e-1), torch.bfloat16: (8e-2, 7e-1)}[dtype]
+    # |g|: 2.2e-4 (round 2) ... 7.1e-4 (round 3, lora variant, feature_projections.0.0.conv3.norm.weight) -> gate 2e-3
+    ntol, ptol = {torch.float32: (2e-3, 8e-3), torch.float16: (4e-2, 3e-1), torch.bfloat16: (8e-2, 7e-1)}[dtype]
     errs = []
     typical = float(_np.median(rows[:, 0][rows[:, 0] > 0]))      # (the zero_grad term's exact zeros aside)
     for n, (norm, dot) in zip(names, rows):
