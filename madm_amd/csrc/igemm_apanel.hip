@@ -81,8 +81,15 @@ template <> __device__ __forceinline__ void ap_store2<bf16_t>(__amdgpu_buffer_rs
 // After the prologue the waves never synchronise: the panel is read-only and every wave streams the weight rows of ITS
 // columns into a private ring (with WM = 2 the two waves of a column half fetch the same rows: twice the weight bytes on
 // the load path, still half of what a 64 x 64 tile moves per FLOP, and no barrier in the loop).
+// Built WITHOUT packed-FP32 VALU ops (device pass only; see csrc/Makefile's note for what was observed with them).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AP_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define AP_NO_PACKED_F32
+#endif
+
 template <typename T, int BM, int WM>
-__global__ __launch_bounds__(256, 2) void igemm_apanel_kernel(const IgemmP p, int tpb, int nchunks) {
+__global__ __launch_bounds__(256, 2) AP_NO_PACKED_F32 void igemm_apanel_kernel(const IgemmP p, int tpb, int nchunks) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int EPC = TT<T>::EPC;
     constexpr int WN = 4 / WM;
