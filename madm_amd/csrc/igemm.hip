@@ -185,11 +185,18 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
                                                                          p.in2 ? p.bytes2 : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.bytesw, 0x00020000);
 
-    const int kt0 = (p.nk * z) / p.splitk;
-    const int kt1 = (p.nk * (z + 1)) / p.splitk;
+    // (integer divisions by run-time values cost ~150 clocks each on this VALU and sit in front of the first load: the
+    // common cases -- no split-K, linear layers -- take none)
+    int kt0 = 0, kt1 = p.nk;
+    if (p.splitk > 1) {
+        kt0 = (p.nk * z) / p.splitk;
+        kt1 = (p.nk * (z + 1)) / p.splitk;
+    }
     // tap state of the NEXT tile to load
     int c0, tr, ts;
-    {
+    if constexpr (LIN) {
+        c0 = kt0 * BKE; tr = 0; ts = 0;      // one tap: k = channel
+    } else {
         const int kbase = kt0 * BKE;
         const int tap = kbase / p.Ctot;
         c0 = kbase - tap * p.Ctot;
@@ -389,11 +396,16 @@ __global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_k
                                                                          p.in2 ? p.bytes2 : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.bytesw, 0x00020000);
 
-    const int kt0 = (p.nk * z) / p.splitk;
-    const int kt1 = (p.nk * (z + 1)) / p.splitk;
+    int kt0 = 0, kt1 = p.nk;     // (no run-time divisions in front of the first load in the common cases, see igemm_kernel)
+    if (p.splitk > 1) {
+        kt0 = (p.nk * z) / p.splitk;
+        kt1 = (p.nk * (z + 1)) / p.splitk;
+    }
     const int nt = kt1 - kt0;
     int c0, tr, ts;   // tap state of the NEXT tile to load
-    {
+    if constexpr (LIN) {
+        c0 = kt0 * BKE; tr = 0; ts = 0;
+    } else {
         const int kbase = kt0 * BKE;
         const int tap = kbase / p.Ctot;
         c0 = kbase - tap * p.Ctot;
