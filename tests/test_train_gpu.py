@@ -382,7 +382,7 @@ def test_trainer_step_with_lora_adapters_only(cuda):
         for a in moved:
             if f".lora_A.{a}." in n or f".lora_B.{a}." in n:
                 if a == "Event":      # zero gradient: p <- p (1 - lr wd), nothing else (m = v = 0 -> update 0)
-                    assert torch.allclose(p.detach(), before[n] * (1 - lr * wd), rtol=0, atol=1e-9), n
+                    assert torch.allclose(p.detach(), before[n] * (1 - lr * wd), rtol=1e-6, atol=0), n      # (an f32 ulp of the product)
                 else:
                     assert not torch.equal(p.detach(), before[n]), n
                 moved[a] += 1
