@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MADM_ABI_VERSION 2
+#define MADM_ABI_VERSION 3
 
 typedef enum {
     MADM_OK = 0,
@@ -133,6 +133,18 @@ typedef struct {
      * splitk == 1 (every workgroup walks whole rows), no fused GroupNorm. */
     const float* ln_colsum;
     float ln_eps;
+    /* GroupNorm(+act) of the OUTPUT applied by the split-K reduction (ABI 3; diffusers ResnetBlock2D conv1 -> norm2 ->
+     * nonlinearity, ldm_diffusers.py runs them as nn.Conv2d + nn.GroupNorm + SiLU): with splitk > 1 the slabs are summed by
+     * one workgroup per (image, group), which holds its HW x N / pn_groups f32 values in LDS, takes the group's mean /
+     * variance from them and stores out = act((v - mean) * rstd * pn_gamma[n] + pn_beta[n]): the raw conv output never
+     * reaches memory and the stand-alone reduction + GroupNorm passes become one launch.  pn_gamma NULL = off.  Needs the
+     * effective splitk > 1, the plain epilogue, no residual / stats / out_f32, N / pn_groups even and the group's values
+     * within 96 KB of LDS (madm_conv2d_can_post_groupnorm tells). */
+    const float* pn_gamma;
+    const float* pn_beta;
+    int pn_groups;
+    float pn_eps;
+    int pn_act;           /* madm_act */
 } madm_conv2d_args;
 
 size_t madm_conv2d_workspace_bytes(const madm_conv2d_args* a);
@@ -141,6 +153,9 @@ int madm_conv2d_suggest_splitk(const madm_conv2d_args* a);
 int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream);
 /* 1 when these arguments can take gn_sums1 / gn_gamma / ... (the LDS halo-tile 3x3 kernel applies), else 0. */
 int madm_conv2d_can_fuse_groupnorm(const madm_conv2d_args* a);
+/* 1 when madm_conv2d_fwd with these arguments (splitk, dims, pn_groups set; pointers not needed) can take pn_gamma / ...,
+ * else 0. */
+int madm_conv2d_can_post_groupnorm(const madm_conv2d_args* a);
 /* which kernel instance madm_conv2d_fwd will launch for these arguments: 1 = igemm 128x128,
  * 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 x128 channels, 5 = halo conv3x3 x64 channels,
  * 6 = igemm 64x64 with the 8-deep prefetch, 7 / 8 = LDS-DMA igemm 64x64 / 128x64,

@@ -55,6 +55,7 @@ class Conv2dArgs(ctypes.Structure):
         ("workspace", c_void_p),
         ("workspace_bytes", c_size_t),
         ("ln_colsum", c_void_p), ("ln_eps", ctypes.c_float),
+        ("pn_gamma", c_void_p), ("pn_beta", c_void_p), ("pn_groups", c_int), ("pn_eps", ctypes.c_float), ("pn_act", c_int),
     ]
 
 
@@ -106,6 +107,7 @@ SYMBOLS = [
     ("madm_conv2d_suggest_splitk", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_pick_tile", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_can_fuse_groupnorm", c_int, [ctypes.POINTER(Conv2dArgs)]),
+    ("madm_conv2d_can_post_groupnorm", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_groupnorm_finalize", c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                         c_float, c_void_p, c_void_p, c_void_p]),
     ("madm_conv2d_fwd", c_int, [ctypes.POINTER(Conv2dArgs), c_void_p]),

@@ -626,6 +626,95 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
     }
 }
 
+// Split-K reduction + the GroupNorm(+act) that consumes the conv (madm_conv2d_args.pn_gamma; ResnetBlock2D conv1 -> norm2 ->
+// SiLU).  One workgroup per (group, image): the slabs of the group's HW x cpg values are summed (in slab order, then + bias
+// + time row: the order of splitk_reduce_kernel) into LDS as f32 pairs; mean / variance come from those f32 values (f32
+// partials of <= 2 * ceil(units / 1024) values per thread, f64 across threads; the algebra of gn_apply_kernel); the second
+// pass normalises out of LDS.  The raw conv output never exists in memory.  Everything it reads was written by the launch
+// before it (L2-resident slabs): a latency kernel, so 16 waves per workgroup with four slab loads in flight each.
+struct PostGn { const float* gamma; const float* beta; int G; float eps; int act; };
+constexpr int PGN_THREADS = 1024;
+constexpr size_t PGN_MAX_LDS = 96 * 1024;
+
+// V = floats per unit (4 when the group's channel count allows 16-byte accesses, else 2).
+template <typename T, int V>
+__global__ __launch_bounds__(PGN_THREADS) void splitk_groupnorm_kernel(const IgemmP p, const PostGn pn) {
+    extern __shared__ __attribute__((aligned(16))) float pgn_vals[];
+    __shared__ double pgn_red[2][PGN_THREADS / 64];
+    __shared__ float pgn_mr[2];
+    typedef float vec __attribute__((ext_vector_type(V)));
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cpg = p.N / pn.G, upp = cpg / V;           // units per pixel
+    const int HW = p.OH * p.OW;
+    const int units = HW * upp;
+    const size_t slab = (size_t)p.M * p.N;
+    const float* base = p.ws + (size_t)b * HW * p.N + g * cpg;
+    float s = 0.f, q = 0.f;
+    // 64 workgroups feed on slabs all 256 CUs just wrote: what bounds this loop is the bytes one CU keeps in flight, so
+    // every thread requests eight slabs of its unit at once (16 waves x 64 lanes x 8 x 16 B = 128 KB per CU)
+    constexpr int SF = 8;
+    for (int u = threadIdx.x; u < units; u += PGN_THREADS) {
+        const int px = u / upp, c = (u - px * upp) * V;
+        const float* src = base + (size_t)px * p.N + c;
+        vec add = {};
+        if (p.bias) add = *reinterpret_cast<const vec*>(p.bias + g * cpg + c);
+        if (p.rowvec) add += *reinterpret_cast<const vec*>(p.rowvec + (size_t)b * p.ldrv + g * cpg + c);
+        vec v = {};
+        for (int z = 0; z < p.splitk; z += SF) {
+            vec t[SF];
+#pragma unroll
+            for (int k = 0; k < SF; ++k) {
+                t[k] = vec{};
+                if (z + k < p.splitk) t[k] = *reinterpret_cast<const vec*>(src + (size_t)(z + k) * slab);
+            }
+#pragma unroll
+            for (int k = 0; k < SF; ++k)
+                if (z + k < p.splitk) v += t[k];         // slab order: the sums of splitk_reduce_kernel, bit for bit
+        }
+        v += add;
+        *reinterpret_cast<vec*>(pgn_vals + (size_t)u * V) = v;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s += v[j]; q = fmaf(v[j], v[j], q); }
+    }
+    double ds = (double)s, dq = (double)q;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
+    if ((threadIdx.x & 63) == 0) { pgn_red[0][threadIdx.x >> 6] = ds; pgn_red[1][threadIdx.x >> 6] = dq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int w = 0; w < PGN_THREADS / 64; ++w) { S += pgn_red[0][w]; Q += pgn_red[1][w]; }
+        const double inv_cnt = 1.0 / ((double)HW * (double)cpg);
+        const double mean = S * inv_cnt;
+        double var = Q * inv_cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        pgn_mr[0] = (float)mean;
+        pgn_mr[1] = __builtin_amdgcn_rsqf((float)var + pn.eps);
+    }
+    __syncthreads();
+    const float mean = pgn_mr[0], rstd = pgn_mr[1];
+    T* ob = reinterpret_cast<T*>(p.out) + (size_t)b * HW * p.ldo + g * cpg;
+    for (int u = threadIdx.x; u < units; u += PGN_THREADS) {
+        const int px = u / upp, c = (u - px * upp) * V;
+        const vec gm = *reinterpret_cast<const vec*>(pn.gamma + g * cpg + c);
+        const vec bt = *reinterpret_cast<const vec*>(pn.beta + g * cpg + c);
+        const vec v = *reinterpret_cast<const vec*>(pgn_vals + (size_t)u * V);
+        float y[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {   // scale / shift formed as in gn_apply_kernel: x (rstd gamma) + (beta - mean rstd gamma)
+            const float sc = rstd * gm[j];
+            y[j] = act_f(v[j] * sc + (bt[j] - mean * sc), pn.act);
+        }
+        T* o = ob + (size_t)px * p.ldo + c;
+        if constexpr (V == 4) store4<T>(o, f32x4{y[0], y[1], y[2], y[3]});
+        else store2<T>(o, y[0], y[1]);
+    }
+}
+
+// can the split-K reduction of this launch apply the consumer's GroupNorm?  (mirrors the clamps of madm_conv2d_fwd)
+inline size_t post_gn_lds(int HW, int N, int G) { return (size_t)HW * (size_t)(N / G) * sizeof(float); }
+
 int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
 inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8) || t == 11; }
 // tile 13 (igemm_apanel.hip): plain linear layer, one source, whole rows resident: no split-K, no residual / time row /
@@ -822,7 +911,7 @@ int launch_glds(const IgemmP& p, dim3 grid, hipStream_t s) {
 }
 
 template <typename T>
-int launch(const IgemmP& p0, int t, hipStream_t s) {
+int launch(const IgemmP& p0, int t, hipStream_t s, const PostGn& pn) {
     IgemmP p = p0;
     int bm, bn;
     tile_dims(t, bm, bn);
@@ -849,7 +938,22 @@ int launch(const IgemmP& p0, int t, hipStream_t s) {
         rc = madm_check_launch("igemm_kernel");
     }
     if (rc) return rc;
-    if (p.splitk > 1) {
+    if (p.splitk > 1 && pn.gamma) {
+        const size_t lds = post_gn_lds(p.OH * p.OW, p.N, pn.G);
+        const dim3 pgrid((unsigned)pn.G, (unsigned)p.B);
+        if ((p.N / pn.G) % 4 == 0) {
+            auto kern = splitk_groupnorm_kernel<T, 4>;
+            static std::atomic<uint64_t> attr_done{0};
+            if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done, "split-K + GroupNorm")) return e;
+            kern<<<pgrid, PGN_THREADS, lds, s>>>(p, pn);
+        } else {
+            auto kern = splitk_groupnorm_kernel<T, 2>;
+            static std::atomic<uint64_t> attr_done{0};
+            if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done, "split-K + GroupNorm")) return e;
+            kern<<<pgrid, PGN_THREADS, lds, s>>>(p, pn);
+        }
+        rc = madm_check_launch("splitk_groupnorm_kernel");
+    } else if (p.splitk > 1) {
         dim3 rgrid((unsigned)((p.N / 4 + 15) / 16), (unsigned)((p.M + 15) / 16));
         splitk_reduce_kernel<T><<<rgrid, 256, 0, s>>>(p);
         rc = madm_check_launch("splitk_reduce_kernel");
@@ -934,10 +1038,33 @@ int madm_conv2d_fwd(const madm_conv2d_args* a, void* stream) {
         const int nchunks = p.Ctot / ((8 * madm_epc(a->dtype)));
         if (p.splitk > nchunks) p.splitk = nchunks;
     }
+    PostGn pn{nullptr, nullptr, 0, 0.f, 0};
+    if (a->pn_gamma) {
+        MADM_REQUIRE(madm_conv2d_can_post_groupnorm(a),
+                     "conv2d: the GroupNorm of the output rides on the split-K reduction: effective splitk > 1, plain "
+                     "epilogue, no residual / stats / out_f32, even N / groups, HW * N / groups * 4 <= %zu bytes of LDS "
+                     "(madm_conv2d_can_post_groupnorm tells)", PGN_MAX_LDS);
+        MADM_REQUIRE(a->pn_beta && a->pn_eps > 0.f && a->pn_act >= 0 && a->pn_act <= 2, "conv2d: bad pn_beta / pn_eps / pn_act");
+        pn = PostGn{a->pn_gamma, a->pn_beta, a->pn_groups, a->pn_eps, a->pn_act};
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (a->dtype == MADM_F32) return launch<float>(p, t, s);
-    if (a->dtype == MADM_F16) return launch<f16_t>(p, t, s);
-    return launch<bf16_t>(p, t, s);
+    if (a->dtype == MADM_F32) return launch<float>(p, t, s, pn);
+    if (a->dtype == MADM_F16) return launch<f16_t>(p, t, s, pn);
+    return launch<bf16_t>(p, t, s, pn);
+}
+
+int madm_conv2d_can_post_groupnorm(const madm_conv2d_args* a) {
+    if (!a || !madm_dtype_ok(a->dtype) || a->splitk <= 1 || a->pn_groups <= 0 || a->N <= 0 || a->N % a->pn_groups) return 0;
+    if (a->epilogue != MADM_EPI_NONE || a->residual || a->stats || a->out_f32 || a->ln_colsum) return 0;
+    const int bke = 8 * madm_epc(a->dtype);
+    const int Ctot = a->C1 + a->C2;
+    int sk = a->splitk;                                   // the clamps of fill_params / madm_conv2d_fwd
+    const int nk = a->KH * a->KW * Ctot / bke;
+    if (sk > nk) sk = nk;
+    if (is_halo_tile(pick_tile(a)) && sk > Ctot / bke) sk = Ctot / bke;
+    if (sk <= 1) return 0;
+    const int cpg = a->N / a->pn_groups;
+    return (cpg % 2 == 0 && post_gn_lds(a->OH * a->OW, a->N, a->pn_groups) <= PGN_MAX_LDS) ? 1 : 0;
 }
 
 int madm_conv2d_can_fuse_groupnorm(const madm_conv2d_args* a) { return a && halo_eligible(a) ? 1 : 0; }

@@ -117,11 +117,13 @@ class Conv2d(_Packed):
         return (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
 
     def forward(self, x, x2=None, upsample=False, rowvec=None, residual=None, out=None, stats=True, norm=None,
-                act=True):
+                act=True, post_norm=None):
         """x (and optional x2 = channel-concatenated second source) are Tok; returns Tok.  ``stats``:
         also emit the GroupNorm statistics of the output from the epilogue (Tok.stats).  ``norm``: a
         GroupNorm module applied (with SiLU when ``act``) to [x | x2] before the conv -- folded into the
-        conv's LDS halo load when the 3x3 halo kernel applies, a separate pass otherwise."""
+        conv's LDS halo load when the 3x3 halo kernel applies, a separate pass otherwise.  ``post_norm``: a GroupNorm
+        module applied (with SiLU) to the OUTPUT: the returned Tok holds silu(post_norm(conv(x))) -- by the conv's split-K
+        reduction when it has one (ops.conv2d post_gn), by a separate pass otherwise."""
         dtype = x.t.dtype
         gn = None
         if norm is not None:
@@ -148,12 +150,21 @@ class Conv2d(_Packed):
         OH, OW = self.out_hw(x.H, x.W, upsample)
         pad = 0 if self.asym_pad else self.padding
         st = ops.new_chsums(x.B, self.n_pad, x.t.device) if (stats and not ops.EXP_NO_STATS) else None
+        post_gn = None
+        if post_norm is not None:
+            assert self.n_pad == self.out_channels and residual is None
+            post_gn = (post_norm.weight.detach(), post_norm.bias.detach(), post_norm.num_groups, post_norm.eps, True)
         o = ops.conv2d(x.t, wp, x.B, x.H, x.W, N=self.n_pad, x2=None if x2 is None else x2.t,
                        KH=self.kernel_size, KW=self.kernel_size, stride=self.stride, pad_t=pad, pad_l=pad,
                        OH=OH, OW=OW, upsample=upsample, bias=b, rowvec=rowvec,
                        residual=None if residual is None else residual.t, out=out,
                        alg_nk=(self.out_channels, self.kernel_size * self.kernel_size * self.in_channels), stats=st,
-                       gn=gn)
+                       gn=gn, post_gn=post_gn)
+        if post_norm is not None:
+            o, applied = o
+            if applied:
+                return Tok(o, x.B, OH, OW)
+            return post_norm(Tok(o, x.B, OH, OW, st), silu=True)
         return Tok(o, x.B, OH, OW, st)
 
 

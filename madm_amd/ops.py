@@ -64,6 +64,8 @@ if os.environ.get("MADM_EXP_SPLITK"):   # experiment: e.g. 1 = no split-K anywhe
 # "attention", "softmax", or tile codes of madm_conv2d_pick_tile ("tile7", ...): what would the step cost without them?
 EXP_SKIP = set(filter(None, os.environ.get("MADM_EXP_SKIP", "").split(",")))
 FUSE_GN = True   # fold GroupNorm(+SiLU) into eligible 3x3 convs (debug switch)
+# the GroupNorm that consumes a split-K conv rides on its reduction (conv2d(post_gn=...)); env MADM_NO_POST_GN for A/B runs
+POST_GN = not bool(int(os.environ.get("MADM_NO_POST_GN", "0")))
 HALO_MIN_W = int(__import__("os").environ.get("MADM_HALO_MIN_W", "8"))   # mirrors halo_min_width() of igemm.hip
 import os as _os
 FUSE_GN_MAX_N = int(_os.environ.get("MADM_FUSE_GN_MAX_N", "256"))   # ... whose output has at most 256 channels: the
@@ -124,9 +126,14 @@ def _workspace(nbytes, device):
 
 def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
            upsample=False, bias=None, rowvec=None, residual=None, epilogue=EPI_NONE, out=None,
-           splitk=None, alg_nk=None, stats=None, gn=None, out_f32=False, ln=None):
+           splitk=None, alg_nk=None, stats=None, gn=None, out_f32=False, ln=None, post_gn=None):
     """Implicit-GEMM conv / linear.  x1: [B*IH*IW, C1] dense; x2 optional second source (concat);
-    w: packed [N, KH*KW*(C1+C2)]; returns out [B*OH*OW, N] (N/2 columns for GEGLU)."""
+    w: packed [N, KH*KW*(C1+C2)]; returns out [B*OH*OW, N] (N/2 columns for GEGLU).
+
+    ``post_gn`` = (gamma, beta, groups, eps, act): the GroupNorm(+act) that CONSUMES this conv, applied by its split-K
+    reduction when the launch has one (madm_conv2d_args.pn_gamma).  Returns (out, applied): ``applied`` False = the launch
+    cannot carry it (no split-K, group too large for LDS): ``out`` is then the raw conv output (with ``stats`` filled, if
+    given) and the caller runs the norm itself; True = ``out`` holds the normalised activations and ``stats`` was not used."""
     _need_cuda(x1, w, x2, bias, rowvec, residual, out)
     C1 = x1.shape[1]
     C2 = 0 if x2 is None else x2.shape[1]
@@ -171,9 +178,6 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     a.out = out.data_ptr()
     a.ldo = out.stride(0)
     a.epilogue = epilogue
-    if stats is not None:
-        assert stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() == B * N * 2
-        a.stats = stats.data_ptr()
     if gn is not None:   # (sums list, gamma, beta, groups, eps, act): GroupNorm(+act) of the input fused into the conv
         sums, gamma, beta, groups, eps, act = gn
         _need_cuda(gamma, beta, *sums)
@@ -198,6 +202,19 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
     if splitk is None:
         splitk = lib.madm_conv2d_suggest_splitk(ctypes.byref(a))
     a.splitk = max(1, int(splitk))
+    applied = False
+    if post_gn is not None:
+        gamma, beta, groups, eps, act = post_gn
+        _need_cuda(gamma, beta)
+        assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.is_contiguous() and beta.is_contiguous()
+        assert gamma.numel() == N and beta.numel() == N and residual is None and ln is None
+        a.pn_groups = int(groups)
+        if POST_GN and lib.madm_conv2d_can_post_groupnorm(ctypes.byref(a)):
+            a.pn_gamma, a.pn_beta, a.pn_eps, a.pn_act = gamma.data_ptr(), beta.data_ptr(), float(eps), _act_code(act=act)
+            applied = True
+    if stats is not None and not applied:
+        assert stats.dtype == torch.float64 and stats.is_contiguous() and stats.numel() == B * N * 2
+        a.stats = stats.data_ptr()
     ws = None
     if a.splitk > 1:
         nbytes = lib.madm_conv2d_workspace_bytes(ctypes.byref(a))
@@ -205,14 +222,14 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
     if EXP_SKIP and ("tile%d" % lib.madm_conv2d_pick_tile(ctypes.byref(a))) in EXP_SKIP:
-        return out
+        return out if post_gn is None else (out, applied)
     if PROFILE is None:
         check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     else:
         an, ak = alg_nk if alg_nk is not None else (N, KH * KW * (C1 + C2))
         name = _TILE_NAMES[lib.madm_conv2d_pick_tile(ctypes.byref(a))] + _SUFFIX[x1.dtype]
         desc = (f"M{M} N{N} K{KH * KW * (C1 + C2)} k{KH} s{stride}{' up' if upsample else ''}"
-                f"{' gn' if gn is not None else ''} sk{a.splitk}")
+                f"{' gn' if gn is not None else ''} sk{a.splitk}{' +gn' if applied else ''}")
         es = x1.element_size()
         # algorithmic HBM bytes: every input element, weight and output element once
         nbytes = (B * IH * IW * (C1 + C2) * es + w.numel() * es
@@ -224,7 +241,7 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
             check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
             pr.e2 = torch.cuda.Event(enable_timing=True)
             pr.e2.record()
-    return out
+    return out if post_gn is None else (out, applied)
 
 
 def linear(x, w, *, bias=None, residual=None, epilogue=EPI_NONE, out=None, x2=None, splitk=None, alg_nk=None,

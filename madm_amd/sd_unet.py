@@ -293,12 +293,18 @@ class ResnetBlock2D(nn.Module):
     def forward(self, x, temb_row=None, skip=None):
         """x (+ optional skip = second concat source) -> Tok.  ``temb_row``: f32 [B, Cout] =
         time_emb_proj(silu(emb)) (computed for all resnets at once by the UNet)."""
-        h = self.conv1(x, x2=skip, norm=self.norm1, rowvec=temb_row)   # GN + SiLU + conv (+ time row)
+        c2 = self.conv2
+        # norm2 + SiLU: folded into conv2's halo load where that pays (narrow layers), otherwise applied by conv1's split-K
+        # reduction when it has one (the raw conv1 output is needed by nothing else), otherwise a pass of its own
+        fold2 = c2.out_channels <= ops.FUSE_GN_MAX_N and ops.can_fuse_groupnorm(
+            x.H, x.W, c2.kernel_size, c2.stride, c2.padding, c2.asym_pad, False)
+        h = self.conv1(x, x2=skip, norm=self.norm1, rowvec=temb_row,          # GN + SiLU + conv (+ time row)
+                       post_norm=None if fold2 else self.norm2)
         if self.conv_shortcut is None:
             res = x
         else:
             res = self.conv_shortcut(x, x2=skip, stats=False)   # 1x1 over the raw (concatenated) input
-        return self.conv2(h, norm=self.norm2, residual=res)
+        return c2(h, norm=self.norm2 if fold2 else None, residual=res)
 
 
 class Downsample2D(nn.Module):

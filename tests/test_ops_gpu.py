@@ -433,6 +433,68 @@ def test_conv_fused_groupnorm_input(cuda, dtype, case):
     assert e < (3e-5 if dtype == torch.float32 else 2e-2), f"{e:.3e} {l2:.3e}"
 
 
+POST_GN_CASES = [
+    # name, B, Cin, H, W, Cout, splitk, tile (0 = table / heuristic), time row, expected "applied"
+    ("unet16_1280", 2, 64, 16, 16, 1280, 4, 0, True, True),       # 40 KB of LDS per group
+    ("unet32_640", 2, 192, 32, 32, 640, 3, 0, True, True),        # 80 KB; halo kernel, three channel chunks in 16-bit modes
+    ("unet8_1280_halo", 1, 128, 8, 8, 1280, 2, 9, False, True),   # the halo kernel's split-K (whole channel chunks)
+    ("ragged_map", 3, 64, 5, 7, 128, 5, 3, True, True),
+    ("ten_channel_groups", 2, 64, 8, 8, 320, 9, 3, True, True),   # 8-byte units (the 16-byte path needs N / groups % 4 == 0)
+    ("clamped_to_one_slab", 2, 64, 8, 8, 128, 4, 9, False, None),  # halo kernel: Cin = 64 is one chunk in 16-bit modes
+    ("no_splitk", 2, 64, 16, 16, 128, 1, 0, True, False),
+    ("group_too_large", 1, 64, 64, 64, 320, 2, 0, False, False),  # 160 KB
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", POST_GN_CASES, ids=[c[0] for c in POST_GN_CASES])
+def test_conv_post_groupnorm_on_the_splitk_reduction(cuda, dtype, case):
+    """conv2d(post_gn=...) == silu(GroupNorm(conv(x) + bias + time row)) (diffusers ResnetBlock2D conv1 -> norm2 ->
+    nonlinearity): applied by the split-K reduction when the launch has one and the group fits LDS; ``applied`` False
+    otherwise, with the raw conv output and its statistics as without post_gn."""
+    from madm_amd import ops, packing
+    from madm_amd._lib import lib
+    name, B, Cin, H, W, Cout, splitk, tile, with_row, expect = case
+    kt = ops.k_tile(dtype)
+    x = _q(_gen((B, Cin, H, W), 1), dtype)
+    w = _q(_gen((Cout, Cin, 3, 3), 2) / math.sqrt(Cin * 9), dtype)
+    bias = _gen((Cout,), 3)
+    row = (0.5 * _gen((B, Cout), 6)) if with_row else None
+    gamma, beta = 1.0 + 0.2 * _gen((Cout,), 4), 0.3 * _gen((Cout,), 5)
+    wp = packing.pack_conv_weight(w, dtype, kt).cuda()
+    st = torch.zeros((B, Cout, 2), device="cuda", dtype=torch.float64)
+    lib.madm_debug_set_conv_tile(tile)
+    try:
+        out, applied = ops.conv2d(to_tokens(x, dtype), wp, B, H, W, N=Cout, KH=3, KW=3, pad_t=1, pad_l=1, bias=bias.cuda(),
+                                  rowvec=None if row is None else row.cuda(), stats=st, splitk=splitk,
+                                  post_gn=(gamma.cuda(), beta.cuda(), 32, 1e-5, True))
+        raw = ops.conv2d(to_tokens(x, dtype), wp, B, H, W, N=Cout, KH=3, KW=3, pad_t=1, pad_l=1, bias=bias.cuda(),
+                         rowvec=None if row is None else row.cuda(), splitk=splitk)
+    finally:
+        lib.madm_debug_set_conv_tile(0)
+    if expect is None:
+        expect = dtype == torch.float32     # K tile of 32 elements: two chunks of Cin = 64 only in f32
+    assert applied == expect, (name, applied)
+    conv_ref = F.conv2d(x, w, bias, padding=1)
+    if row is not None:
+        conv_ref = conv_ref + row[:, :, None, None]
+    if not applied:
+        assert torch.equal(out, raw)
+        assert rel_err(st.float().cpu()[..., 0], conv_ref.sum((2, 3)))[0] < (1e-4 if dtype == torch.float32 else 2e-2)
+        return
+    assert float(st.abs().max()) == 0.0     # the statistics buffer is not touched on the merged path
+    ref = F.silu(F.group_norm(conv_ref, 32, gamma, beta, eps=1e-5))
+    e, l2 = rel_err(from_tokens(out, B, H, W), ref)
+    assert e < (3e-5 if dtype == torch.float32 else 2e-2), f"{e:.3e} {l2:.3e}"
+    # and against the two-launch composition on the same slabs: the merged kernel normalises the f32 sums, the
+    # composition the values rounded to the compute dtype -- equal up to that rounding (f32: up to summation order)
+    st2 = torch.zeros((B, Cout, 2), device="cuda", dtype=torch.float64)
+    ops.groupnorm_stats(raw, B, H * W, st2)
+    two = ops.groupnorm(raw, B, H * W, 32, gamma.cuda(), beta.cuda(), 1e-5, silu=True, stats=[st2])
+    e2, _ = rel_err(out.float().cpu(), two.float().cpu())
+    assert e2 < (2e-5 if dtype == torch.float32 else 2e-2), f"{e2:.3e}"
+
+
 WGRAD_CASES = [
     # name, B, Cin(list), H, W, Cout, KH, stride, pad_mode, upsample, splitm
     ("3x3_s1", 2, [64], 8, 8, 64, 3, 1, "same", False, 0),
