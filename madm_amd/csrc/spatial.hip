@@ -114,17 +114,29 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ x,
 // that comb share their taps, so the thread loads (PX + 2) x 3 input chunks for PX outputs -- 4.5 loads per output at
 // PX = 4 instead of 9.  The plain kernel re-fetches every input element nine times through the L1 / L2 path and ran at
 // 1.85 ms for the head's 1 GB tensor (0.5 ms of HBM time); used when the map is at least 4 dilations wide.
-template <typename T, int PX>
+//
+// XCD: workgroups go round-robin to the 8 XCDs, so the threads that share an input element -- the neighbours one dilation
+// up / down / sideways -- sat behind eight different L2s and every one of the 4.5 requests per element crossed the fabric.
+// With XCD = true workgroup g serves channel slab g % 8 (C / 8 channels, >= 128 B per pixel) of ALL pixels: whatever
+// re-reads an element runs on the same XCD, a few rows away in time.  Head tensor (512 x 512 x 1024 f16, 0.5 GB): 450 ->
+// 390 us at dilation 6, 430 -> 400 at 12, 460 -> 430 at 18 (tools/exp/dwconv_ab.py).  Rejected on the same tensor: a
+// column walk with the three input rows held in registers (1.5 requests per element, but 256 VGPRs: 670 us) and
+// requesting all 18 chunks up front with the taps in LDS (214 VGPRs, two workgroups per CU: 450 us).
+template <typename T, int PX, bool XCD>
 __global__ __launch_bounds__(256) void dwconv3x3_comb_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ scale, const float* __restrict__ shift,
                                                              T* __restrict__ y, int ldy, int B, int H, int W, int C, int dil,
                                                              int act, int kblocks) {
     constexpr int EPC = TT<T>::EPC;
     const unsigned CPR = (unsigned)C / EPC;
-    const size_t total = (size_t)B * H * dil * kblocks * CPR;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const unsigned q = (unsigned)(idx % CPR);
-        size_t t = idx / CPR;
+    const unsigned QL = XCD ? CPR / 8 : CPR;                      // channel chunks per slab
+    const unsigned slab = XCD ? (blockIdx.x & 7u) : 0u;
+    const size_t total = (size_t)B * H * dil * kblocks * QL;      // threads' worth of work per slab
+    const size_t first = (size_t)(XCD ? blockIdx.x >> 3 : blockIdx.x) * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)(XCD ? gridDim.x >> 3 : gridDim.x) * blockDim.x;
+    for (size_t idx = first; idx < total; idx += stride) {
+        const unsigned q = slab * QL + (unsigned)(idx % QL);
+        size_t t = idx / QL;
         const int kb = (int)(t % (unsigned)kblocks); t /= (unsigned)kblocks;
         const int r = (int)(t % (unsigned)dil); t /= (unsigned)dil;
         const int oy = (int)(t % (unsigned)H);
@@ -309,13 +321,25 @@ int madm_dwconv3x3(int dtype, const void* x, const float* w, const float* scale,
     const size_t total = (size_t)B * H * W * (C / epc);
     MADM_REQUIRE(total < 0x7fffffffull, "dwconv3x3: tensor too large for 32-bit indexing");
     hipStream_t s = (hipStream_t)stream;
-    if (W >= 4 * dilation) {
+    // MADM_DWCONV_KERNEL (tests, A/B runs): 0 / unset = choose, 1 = plain, 2 = comb, 3 = comb with per-XCD channel slabs
+    const char* fe = getenv("MADM_DWCONV_KERNEL");
+    const int force = fe ? atoi(fe) : 0;
+    if (force != 1 && W >= 4 * dilation) {
         constexpr int PX = 4;
         const int kmax = (W + dilation - 1) / dilation;                  // outputs per residue class (upper bound)
         const int kblocks = (kmax + PX - 1) / PX;
         const size_t tot = (size_t)B * H * dilation * kblocks * (C / epc);
-        MADM_DISPATCH_DTYPE(dtype, (dwconv3x3_comb_kernel<T, PX><<<grid_for(tot, 65536), 256, 0, s>>>(
-                                       (const T*)x, w, scale, shift, (T*)y, ldy, B, H, W, C, dilation, act, kblocks)));
+        // slabs of at least 128 B per pixel, and enough work for eight workgroups per CU
+        const bool slabs = (C / epc) % 8 == 0 &&
+                           (force == 3 || (force == 0 && C / 8 * madm_esize(dtype) >= 128 && tot >= ((size_t)1 << 19)));
+        if (slabs) {
+            const unsigned g = (grid_for(tot, 65536) + 7u) & ~7u;
+            MADM_DISPATCH_DTYPE(dtype, (dwconv3x3_comb_kernel<T, PX, true><<<g, 256, 0, s>>>(
+                                           (const T*)x, w, scale, shift, (T*)y, ldy, B, H, W, C, dilation, act, kblocks)));
+        } else {
+            MADM_DISPATCH_DTYPE(dtype, (dwconv3x3_comb_kernel<T, PX, false><<<grid_for(tot, 65536), 256, 0, s>>>(
+                                           (const T*)x, w, scale, shift, (T*)y, ldy, B, H, W, C, dilation, act, kblocks)));
+        }
         return madm_check_launch("dwconv3x3_comb_kernel");
     }
     MADM_DISPATCH_DTYPE(dtype, (dwconv3x3_kernel<T><<<grid_for(total, 16384), 256, 0, s>>>((const T*)x, w, scale, shift, (T*)y,
