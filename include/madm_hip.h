@@ -384,6 +384,19 @@ typedef struct {
 } madm_conv2d_wgrad_args;
 int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream);
 int madm_pack_dgrad_weights(int dtype, const void* w, void* wt, int N, int taps, int C, void* stream);
+/* f32 master weight (nn.Conv2d [N][Cin][KH][KW] with taps = KH * KW <= 9, nn.Linear: taps = 1) -> the packed forward
+ * operand [N][taps][padded channels] of dtype, row stride ldo: the Cin channels are nsrc <= 4 concatenated sources of
+ * src_channels[s] channels, each zero-padded to ktile (the K order of madm_conv2d_fwd's two-source gather).  interleave: out
+ * row r <- w row (r & 1 ? N / 2 : 0) + r / 2 (diffusers GEGLU.proj: value_j / gate_j rows side by side).  The reference
+ * keeps its weights in torch layouts (nn.Conv2d / nn.Linear inside diffusers, ldm_diffusers.py:60-75); after every
+ * optimizer step (engine/train_loop.py:286) the packed copies are re-derived -- one launch per tensor. */
+int madm_pack_weight(int dtype, const float* w, void* out, int ldo, int N, int Cin, int taps, int nsrc,
+                     const int* src_channels, int ktile, int interleave, void* stream);
+/* the operands of a LayerNorm-folded linear layer (madm_conv2d_args.ln_colsum) from the f32 masters, one launch:
+ * out [N][K] = dtype(w * gamma), bias_out [N] = w beta + b (f64 accumulation; b may be NULL), colsum [N] = row sums of the
+ * ROUNDED out (f64).  K = the normalised width, a multiple of the K tile; interleave as in madm_pack_weight. */
+int madm_fold_layernorm_pack(int dtype, const float* w, const float* b, const float* gamma, const float* beta, void* out,
+                             float* bias_out, float* colsum, int N, int K, int interleave, void* stream);
 /* Data gradient of the other two conv geometries, reduced to the stride-1 case:
  *   stride-2 conv (UNet Downsample2D pad 1, VAE Downsample2D pad (0,1,0,1)): y [B][H][W][C] = dout [B][OH][OW][C]
  *     zero-inserted (y[2 oy][2 ox] = dout[oy][ox], 0 elsewhere), then the stride-1 data gradient with pad' = 2 - pad;

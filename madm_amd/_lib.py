@@ -161,6 +161,10 @@ SYMBOLS = [
     ("madm_nchw_f32_to_nhwc", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     ("madm_conv2d_wgrad", c_int, [ctypes.POINTER(Conv2dWgradArgs), c_void_p]),
     ("madm_pack_dgrad_weights", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    ("madm_pack_weight", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), c_int,
+                                 c_int, c_void_p]),
+    ("madm_fold_layernorm_pack", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_int, c_int, c_void_p]),
     ("madm_attention_bwd_workspace_bytes", c_size_t, [ctypes.POINTER(AttentionBwdArgs)]),
     ("madm_attention_bwd", c_int, [ctypes.POINTER(AttentionBwdArgs), c_void_p]),
     ("madm_zero_insert2x", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -265,6 +265,78 @@ __global__ __launch_bounds__(256) void pack_dgrad_weights_kernel(const T* __rest
     }
 }
 
+// f32 master weights -> the packed forward operand of madm_conv2d_fwd, one launch per tensor (after every optimizer step
+// all ~700 weights are re-derived: as torch ops that was cat + permute + copy + cast + copy per tensor, 2 200 launches and
+// 12 ms of a 254 ms training step):  out[n][(tap, padded channel)] = w[row(n)][channel][tap], the channels of every
+// concatenated source zero-padded to the K tile.  Block = (output row, 256 padded channels of one source): the
+// [channel][tap] block of the row is contiguous in w -> staged through LDS, written tap-major.
+// interleave: out row r <- w row (r & 1 ? N / 2 : 0) + r / 2 (GEGLU: value_j / gate_j rows side by side).
+struct PackP {
+    const float* w; void* out;
+    int N, Cin, taps, nsrc, ldo, cpad_tot, interleave;
+    int C[4], coff[4], cpad[4], cpoff[4];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const PackP p) {
+    __shared__ float st[256 * 9];
+    const int n = blockIdx.x;
+    int y = blockIdx.y, s = 0;
+    while (s < p.nsrc - 1 && y >= (p.cpad[s] + 255) / 256) { y -= (p.cpad[s] + 255) / 256; ++s; }
+    const int cp0 = y * 256;
+    const int row = p.interleave ? ((n & 1) ? p.N / 2 : 0) + (n >> 1) : n;
+    int cvalid = p.C[s] - cp0;                        // real channels in this block (the rest is padding)
+    cvalid = cvalid < 0 ? 0 : (cvalid > 256 ? 256 : cvalid);
+    const float* src = p.w + ((size_t)row * p.Cin + p.coff[s] + cp0) * p.taps;
+    for (int i = threadIdx.x; i < cvalid * p.taps; i += 256) st[i] = src[i];
+    __syncthreads();
+    int cw = p.cpad[s] - cp0;
+    cw = cw > 256 ? 256 : cw;
+    T* orow = reinterpret_cast<T*>(p.out) + (size_t)n * p.ldo + p.cpoff[s] + cp0;
+    for (int i = threadIdx.x; i < cw * p.taps; i += 256) {
+        const int tap = i / cw, c = i - tap * cw;
+        TT<T>::st(orow + (size_t)tap * p.cpad_tot + c, c < cvalid ? st[c * p.taps + tap] : 0.f);
+    }
+}
+
+// LayerNorm folded into the Linear that consumes it (madm_conv2d_args.ln_colsum), one launch per layer:
+//   out[n][k] = T(w[row(n)][k] * gamma[k])   (the f32 product, then rounded to T)
+//   bias'[n]  = sum_k w[row(n)][k] * beta[k] + b[row(n)]           (f64 accumulation)
+//   colsum[n] = sum_k out[n][k]                                    (f64 sum of the ROUNDED weights: exact)
+// one workgroup per output row.
+template <typename T>
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             T* __restrict__ out, float* __restrict__ bias_out,
+                                                             float* __restrict__ colsum, int N, int K, int interleave) {
+    __shared__ double red[2][4];
+    const int n = blockIdx.x;
+    const int row = interleave ? ((n & 1) ? N / 2 : 0) + (n >> 1) : n;
+    const float* src = w + (size_t)row * K;
+    double cs = 0.0, bs = 0.0;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float wv = src[k];
+        float pr = wv * gamma[k];
+        asm volatile("" : "+v"(pr));     // the f32 product, THEN the rounding to T (not one fused f16 rounding: v_fma_mixlo_f16)
+        T q;
+        TT<T>::st(&q, pr);
+        out[(size_t)n * K + k] = q;
+        cs += (double)TT<T>::ld(&q);
+        bs += (double)wv * (double)beta[k];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { cs += __shfl_xor(cs, o); bs += __shfl_xor(bs, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cs; red[1][threadIdx.x >> 6] = bs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double c = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        double bb = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        if (b) bb += (double)b[row];
+        colsum[n] = (float)c;
+        bias_out[n] = (float)bb;
+    }
+}
+
 // y[b][iy][ix][:] = x[b][iy / 2][ix / 2][:] on even (iy, ix) inside the source, 0 elsewhere (16-byte chunks): the
 // zero-inserted output gradient that turns the data gradient of a stride-2 conv into a stride-1 one
 template <typename T>
@@ -497,6 +569,44 @@ extern "C" int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream) 
     else if (a->dtype == MADM_F16) conv2d_wgrad_kernel<f16_t><<<grid, 256, 0, s>>>(p);
     else conv2d_wgrad_kernel<float><<<grid, 256, 0, s>>>(p);
     return madm_check_launch("conv2d_wgrad_kernel");
+}
+
+extern "C" int madm_pack_weight(int dtype, const float* w, void* out, int ldo, int N, int Cin, int taps, int nsrc,
+                               const int* src_channels, int ktile, int interleave, void* stream) {
+    MADM_REQUIRE(w && out && src_channels && N > 0 && Cin > 0, "pack_weight: bad argument");
+    MADM_REQUIRE(madm_dtype_ok(dtype), "pack_weight: unknown dtype %d", dtype);
+    MADM_REQUIRE(taps >= 1 && taps <= 9 && nsrc >= 1 && nsrc <= 4 && ktile > 0, "pack_weight: taps <= 9, 1 .. 4 sources");
+    MADM_REQUIRE(!interleave || N % 2 == 0, "pack_weight: interleaved halves need an even row count");
+    PackP p;
+    p.w = w; p.out = out; p.N = N; p.Cin = Cin; p.taps = taps; p.nsrc = nsrc; p.ldo = ldo; p.interleave = interleave ? 1 : 0;
+    int c0 = 0, cp0 = 0;
+    unsigned blocks = 0;
+    for (int s = 0; s < 4; ++s) {
+        p.C[s] = s < nsrc ? src_channels[s] : 0;
+        MADM_REQUIRE(s >= nsrc || p.C[s] > 0, "pack_weight: empty source");
+        p.coff[s] = c0; p.cpoff[s] = cp0;
+        p.cpad[s] = (p.C[s] + ktile - 1) / ktile * ktile;
+        c0 += p.C[s]; cp0 += p.cpad[s];
+        if (s < nsrc) blocks += (unsigned)((p.cpad[s] + 255) / 256);
+    }
+    MADM_REQUIRE(c0 == Cin, "pack_weight: the sources hold %d channels, the weight %d", c0, Cin);
+    p.cpad_tot = cp0;
+    MADM_REQUIRE(ldo >= taps * cp0, "pack_weight: ldo = %d < %d packed columns", ldo, taps * cp0);
+    MADM_REQUIRE(blocks <= 65535, "pack_weight: grid too large");
+    dim3 grid((unsigned)N, blocks);
+    MADM_DISPATCH_DTYPE(dtype, (pack_weight_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>(p)));
+    return madm_check_launch("pack_weight_kernel");
+}
+
+extern "C" int madm_fold_layernorm_pack(int dtype, const float* w, const float* b, const float* gamma, const float* beta,
+                                       void* out, float* bias_out, float* colsum, int N, int K, int interleave,
+                                       void* stream) {
+    MADM_REQUIRE(w && gamma && beta && out && bias_out && colsum && N > 0 && K > 0, "fold_layernorm_pack: bad argument");
+    MADM_REQUIRE(madm_dtype_ok(dtype), "fold_layernorm_pack: unknown dtype %d", dtype);
+    MADM_REQUIRE(!interleave || N % 2 == 0, "fold_layernorm_pack: interleaved halves need an even row count");
+    MADM_DISPATCH_DTYPE(dtype, (fold_layernorm_kernel<T><<<(unsigned)N, 256, 0, (hipStream_t)stream>>>(
+                                   w, b, gamma, beta, (T*)out, bias_out, colsum, N, K, interleave ? 1 : 0)));
+    return madm_check_launch("fold_layernorm_kernel");
 }
 
 extern "C" int madm_pack_dgrad_weights(int dtype, const void* w, void* wt, int N, int taps, int C, void* stream) {

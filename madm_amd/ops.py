@@ -303,6 +303,42 @@ def conv2d_wgrad(x1, dout, B, IH, IW, *, x2=None, KH=1, KW=1, stride=1, pad_t=0,
     return dw
 
 
+def pack_weight(w, dtype, ktile, splits=None, interleave=False):
+    """f32 master weight on the GPU ([N, Cin, KH, KW] conv or [N, K] linear) -> the packed forward operand
+    [N, KH*KW*sum(pad(splits))] of ``dtype`` in one launch (packing.pack_conv_weight / pack_linear_weight / the row
+    interleave of pack_geglu_weight are the torch statements of the same layout)."""
+    _need_cuda(w)
+    assert w.dtype == torch.float32 and w.dim() in (2, 4)
+    w = w.contiguous()
+    N, Cin = w.shape[0], w.shape[1]
+    taps = 1 if w.dim() == 2 else w.shape[2] * w.shape[3]
+    splits = [Cin] if splits is None else [int(c) for c in splits]
+    assert sum(splits) == Cin and 1 <= len(splits) <= 4 and taps <= 9
+    cols = taps * sum((c + ktile - 1) // ktile * ktile for c in splits)
+    out = torch.empty((N, cols), dtype=dtype, device=w.device)
+    arr = (ctypes.c_int * len(splits))(*splits)
+    check(lib.madm_pack_weight(dtype_code(dtype), w.data_ptr(), out.data_ptr(), cols, N, Cin, taps, len(splits), arr,
+                               int(ktile), 1 if interleave else 0, _stream()), "madm_pack_weight")
+    return out
+
+
+def fold_layernorm_pack(w, b, gamma, beta, dtype, interleave=False):
+    """(W' = dtype(w * gamma) [N, K], bias' = w beta + b f32 [N], colsum of the rounded W' f32 [N]) in one launch
+    (packing.fold_layernorm is the torch statement)."""
+    _need_cuda(w, b, gamma, beta)
+    assert w.dtype == torch.float32 and w.dim() == 2 and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    w, gamma, beta = w.contiguous(), gamma.contiguous(), beta.contiguous()
+    N, K = w.shape
+    assert gamma.numel() == K and beta.numel() == K and (b is None or (b.dtype == torch.float32 and b.numel() == N))
+    out = torch.empty((N, K), dtype=dtype, device=w.device)
+    bias = torch.empty((N,), dtype=torch.float32, device=w.device)
+    cs = torch.empty((N,), dtype=torch.float32, device=w.device)
+    check(lib.madm_fold_layernorm_pack(dtype_code(dtype), w.data_ptr(), None if b is None else b.contiguous().data_ptr(),
+                                       gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), bias.data_ptr(), cs.data_ptr(), N, K,
+                                       1 if interleave else 0, _stream()), "madm_fold_layernorm_pack")
+    return out, bias, cs
+
+
 def pack_dgrad_weights(w, taps):
     """w [N, taps*C] (the packed forward layout) -> wt [C, taps*N] with the taps reversed: the weights with which
     :func:`conv2d` applied to dout (pad' = K - 1 - pad) computes the data gradient of a stride-1 conv / linear."""

@@ -207,13 +207,9 @@ class GEGLU(_Packed):
     def forward(self, x, ln=None):
         if ln is not None:     # raw rows in, LayerNorm folded into the projection (packing.fold_layernorm)
             def build_ln():
-                w = self.proj.weight.detach().float()
-                b = self.proj.bias.detach().float()
-                N, half = w.shape[0], w.shape[0] // 2
-                wi = torch.stack([w[:half], w[half:]], dim=1).reshape(N, w.shape[1])     # (value_j, gate_j) rows
-                bi = torch.stack([b[:half], b[half:]], dim=1).reshape(N)
-                return packing.fold_layernorm(wi, bi, ln.weight.detach().float(), ln.bias.detach().float(), x.dtype,
-                                              ops.k_tile(x.dtype))
+                return packing.fold_layernorm(self.proj.weight.detach().float(), self.proj.bias.detach().float(),
+                                              ln.weight.detach().float(), ln.bias.detach().float(), x.dtype,
+                                              ops.k_tile(x.dtype), interleave=True)     # (value_j, gate_j) rows
             ver = self._versions() + (ln.weight._version, ln.bias._version, ln.weight.data_ptr())
             w, b, cs = self._cache_get((x.dtype, "ln"), build_ln, ver=ver)
             return ops.linear(x, w, bias=b, epilogue=EPI_GEGLU, ln=(cs, ln.eps))

@@ -433,6 +433,38 @@ def test_conv_fused_groupnorm_input(cuda, dtype, case):
     assert e < (3e-5 if dtype == torch.float32 else 2e-2), f"{e:.3e} {l2:.3e}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+def test_weight_packing_kernels_equal_the_torch_statements(cuda, dtype):
+    """madm_pack_weight / madm_fold_layernorm_pack (what the modules use for weights that live on the GPU) produce the
+    layouts packing.py states in torch (run here on the CPU copies): bit for bit, except the f64-accumulated folded bias."""
+    from madm_amd import ops, packing
+    kt = ops.k_tile(dtype)
+    g = torch.Generator().manual_seed(11)
+    # conv weights: one source, padded source, two / three concatenated sources (UNet up blocks), 1x1, N not a multiple of 32
+    for (N, splits, k) in [(64, [64], 3), (36, [4], 3), (320, [640, 320], 3), (68, [100, 28, 64], 1), (128, [300], 1)]:
+        w = torch.randn((N, sum(splits), k, k), generator=g)
+        ref = packing.pack_conv_weight(w, dtype, kt, splits)
+        got = packing.pack_conv_weight(w.cuda(), dtype, kt, splits)
+        assert got.is_cuda and got.shape == ref.shape and torch.equal(got.cpu(), ref), (N, splits, k)
+    for (N, K) in [(320, 320), (77, 768), (10, 100)]:                      # linear, K padded to the tile
+        w = torch.randn((N, K), generator=g)
+        assert torch.equal(packing.pack_linear_weight(w.cuda(), dtype, kt).cpu(), packing.pack_linear_weight(w, dtype, kt))
+    w, b = torch.randn((2560, 320), generator=g), torch.randn((2560,), generator=g)      # GEGLU row interleave
+    rw, rb = packing.pack_geglu_weight(w, b, dtype, kt)
+    gw, gb = packing.pack_geglu_weight(w.cuda(), b.cuda(), dtype, kt)
+    assert torch.equal(gw.cpu(), rw) and torch.equal(gb.cpu(), rb)
+    # folded LayerNorm: plain rows (fused Q/K/V), no bias (cross-attention to_q), GEGLU order
+    for (N, K, with_b, inter) in [(960, 320, True, False), (640, 640, False, False), (2560, 320, True, True)]:
+        w = torch.randn((N, K), generator=g) / K ** 0.5
+        b = torch.randn((N,), generator=g) if with_b else None
+        gamma, beta = 1 + 0.2 * torch.randn((K,), generator=g), 0.3 * torch.randn((K,), generator=g)
+        rW, rB, rC = packing.fold_layernorm(w, b, gamma, beta, dtype, kt, interleave=inter)
+        gW, gB, gC = packing.fold_layernorm(w.cuda(), None if b is None else b.cuda(), gamma.cuda(), beta.cuda(), dtype, kt,
+                                            interleave=inter)
+        assert torch.equal(gW.cpu(), rW) and torch.equal(gC.cpu(), rC), (N, K)
+        assert rel_err(gB.cpu(), rB)[0] < 1e-6, (N, K)
+
+
 POST_GN_CASES = [
     # name, B, Cin, H, W, Cout, splitk, tile (0 = table / heuristic), time row, expected "applied"
     ("unet16_1280", 2, 64, 16, 16, 1280, 4, 0, True, True),       # 40 KB of LDS per group
