@@ -188,6 +188,11 @@ int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int 
                          int c_off, int Ctot, int G, const double* sums1, int C1, const double* sums2,
                          const float* gamma, const float* beta, float eps, int act,
                          const void* residual, int ldres, void* stream);
+/* both sources of a channel-concatenated input ([x1 | x2], UNet up-block resnets: torch.cat([hidden, skip]) then
+ * ResnetBlock2D.norm1) in ONE launch: y[:, :C1] / y[:, C1:] = act(GroupNorm([x1 | x2])), groups over the concatenation. */
+int madm_groupnorm_apply_cat(int dtype, const void* x1, const void* x2, void* y, int ldy, int B, int HW, int C1, int C2,
+                             int G, const double* sums1, const double* sums2, const float* gamma, const float* beta,
+                             float eps, int act, void* stream);
 
 /* channel sums -> the per-(image, channel) affine of the GroupNorm, scale/shift f32 [B][Ctot]:
  * y = x * scale + shift == (x - mean_g) * rstd_g * gamma + beta (what the fused conv computes in its prologue). */

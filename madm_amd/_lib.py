@@ -116,6 +116,8 @@ SYMBOLS = [
     ("madm_groupnorm_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int,
                                      c_void_p]),
+    ("madm_groupnorm_apply_cat", c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),
     ("madm_layernorm_fwd", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
                                    c_void_p]),
     ("madm_softmax_rows", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

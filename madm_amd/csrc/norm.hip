@@ -61,8 +61,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                        const double* __restrict__ sums2,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int act,
-                                                       const T* __restrict__ res, int ldres) {
+                                                       const T* __restrict__ res, int ldres, const T* __restrict__ xsrc2) {
     constexpr int EPC = TT<T>::EPC;
+    if (xsrc2 && blockIdx.z == 1) {      // both sources of a concatenated input in one launch: grid.z picks the source
+        x = xsrc2; c_off = C1; C = Ctot - C1;
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];  // scale[C], shift[C], gmean[G], grstd[G]
     float* scale = lds;
     float* shift = lds + C;
@@ -391,7 +394,33 @@ int madm_groupnorm_apply(int dtype, const void* x, void* y, int ldy, int B, int 
     hipStream_t s = (hipStream_t)stream;
     MADM_DISPATCH_DTYPE(dtype, (gn_apply_kernel<T><<<grid, 256, shm, s>>>((const T*)x, (T*)y, ldy, HW, C, c_off, Ctot, G,
                                                                         sums1, C1, sums2, gamma, beta, eps, act,
-                                                                        (const T*)residual, ldres)));
+                                                                        (const T*)residual, ldres, (const T*)nullptr)));
+    return madm_check_launch("gn_apply_kernel");
+}
+
+int madm_groupnorm_apply_cat(int dtype, const void* x1, const void* x2, void* y, int ldy, int B, int HW, int C1, int C2,
+                             int G, const double* sums1, const double* sums2, const float* gamma, const float* beta,
+                             float eps, int act, void* stream) {
+    MADM_REQUIRE(x1 && x2 && y && sums1 && sums2 && gamma && beta, "groupnorm_apply_cat: null pointer");
+    const int Ctot = C1 + C2;
+    MADM_REQUIRE(B > 0 && HW > 0 && C1 > 0 && C2 > 0 && G > 0 && Ctot % G == 0 && ldy >= Ctot, "groupnorm_apply_cat: bad dims");
+    const int epc = madm_epc(dtype);
+    MADM_REQUIRE(C1 % epc == 0 && C2 % epc == 0 && ldy % epc == 0, "groupnorm_apply_cat: C1/C2/ldy must be multiples of %d", epc);
+    MADM_REQUIRE(act >= 0 && act <= 2, "groupnorm_apply_cat: bad act");
+    const int Cmax = C1 > C2 ? C1 : C2;
+    const size_t shm = ((size_t)2 * Cmax + 2 * G) * sizeof(float);
+    MADM_REQUIRE(shm <= 64 * 1024, "groupnorm_apply_cat: C=%d too large", Cmax);
+    const size_t total = (size_t)HW * (Cmax / epc);
+    MADM_REQUIRE(total < 0x7fffffffull, "groupnorm_apply_cat: tensor too large for 32-bit indexing");
+    size_t strips = (total + 256 * 4 - 1) / (256 * 4);
+    const size_t maxstrips = (size_t)(2048 + 2 * B - 1) / (2 * B);
+    if (strips > maxstrips) strips = maxstrips;
+    if (strips < 1) strips = 1;
+    dim3 grid((unsigned)strips, (unsigned)B, 2u);
+    hipStream_t s = (hipStream_t)stream;
+    MADM_DISPATCH_DTYPE(dtype, (gn_apply_kernel<T><<<grid, 256, shm, s>>>((const T*)x1, (T*)y, ldy, HW, C1, 0, Ctot, G, sums1, C1,
+                                                                        sums2, gamma, beta, eps, act, (const T*)nullptr, 0,
+                                                                        (const T*)x2)));
     return madm_check_launch("gn_apply_kernel");
 }
 

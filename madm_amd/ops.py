@@ -511,6 +511,13 @@ def groupnorm(xs, B, HW, G, gamma, beta, eps, silu=False, stats=None, act=None, 
     C1 = xs[0].shape[1]
     s2 = stats[1].data_ptr() if len(xs) > 1 else None
     off = 0
+    if len(xs) == 2 and residual is None and "gn_apply" not in EXP_SKIP:      # both sources in one launch
+        assert xs[0].is_contiguous() and xs[1].is_contiguous()
+        check(lib.madm_groupnorm_apply_cat(dtype_code(xs[0]), xs[0].data_ptr(), xs[1].data_ptr(), out.data_ptr(), out.stride(0),
+                                           B, HW, C1, xs[1].shape[1], G, stats[0].data_ptr(), s2, gamma.data_ptr(),
+                                           beta.data_ptr(), float(eps), _act_code(silu, act), _stream()),
+              "madm_groupnorm_apply_cat")
+        return out
     for x in xs:
         assert x.is_contiguous()
         if "gn_apply" in EXP_SKIP:
