@@ -159,6 +159,37 @@ def test_packing_layouts():
     assert torch.equal(pg[0::2, :6], wl[:4]) and torch.equal(pg[1::2, :6], wl[4:])
     assert torch.equal(bg[0::2], bl[:4]) and torch.equal(bg[1::2], bl[4:])
     assert packing.pack_linear_weight(torch.randn(3, 70), torch.bfloat16, 64).shape == (3, 128)
+    # folded LayerNorm: Linear(LN(x)) == rstd (x W'^T - mean colsum) + bias'; ``interleave`` == the GEGLU row order first
+    g = torch.Generator().manual_seed(3)
+    x, w, b = torch.randn((5, 64), generator=g), torch.randn((8, 64), generator=g), torch.randn((8,), generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn((64,), generator=g), 0.1 * torch.randn((64,), generator=g)
+    W, B, C = packing.fold_layernorm(w, b, gamma, beta, torch.float32, 32)
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    got = (x @ W.t() - mean * C[None, :]) / torch.sqrt(var + 1e-5) + B[None, :]
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (64,), gamma, beta, 1e-5), w, b)
+    assert torch.allclose(got, ref, atol=2e-5)
+    Wi, Bi, Ci = packing.fold_layernorm(w, b, gamma, beta, torch.float32, 32, interleave=True)
+    assert torch.equal(Wi[0::2], W[:4]) and torch.equal(Wi[1::2], W[4:]) and torch.equal(Bi[0::2], B[:4])
+    assert torch.equal(Ci[1::2], C[4:])
+
+
+def test_pack_entry_points_validate_arguments_without_gpu():
+    from madm_amd._lib import lib
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.addressof(buf)
+    one = (ctypes.c_int * 1)(8)
+    assert lib.madm_pack_weight(1, p, p, 64, 4, 8, 25, 1, one, 64, 0, None) == -1 and b"taps <= 9" in lib.madm_last_error()
+    assert lib.madm_pack_weight(1, p, p, 64, 4, 9, 1, 1, one, 64, 0, None) == -1 and b"sources hold" in lib.madm_last_error()
+    assert lib.madm_pack_weight(1, p, p, 32, 4, 8, 1, 1, one, 64, 0, None) == -1 and b"ldo" in lib.madm_last_error()
+    assert lib.madm_pack_weight(1, p, p, 64, 3, 8, 1, 1, one, 64, 1, None) == -1 and b"even row count" in lib.madm_last_error()
+    assert lib.madm_fold_layernorm_pack(1, p, None, None, p, p, p, p, 4, 64, 0, None) == -1
+    a = __import__("madm_amd._lib", fromlist=["Conv2dArgs"]).Conv2dArgs()
+    assert lib.madm_conv2d_can_post_groupnorm(ctypes.byref(a)) == 0          # no split-K, no groups: cannot carry the norm
+    a.dtype, a.splitk, a.pn_groups, a.N, a.C1, a.KH, a.KW, a.OH, a.OW, a.IH, a.IW, a.B = 1, 4, 32, 1280, 512, 1, 1, 16, 16, 16, 16, 2
+    assert lib.madm_conv2d_can_post_groupnorm(ctypes.byref(a)) == 1          # 16 x 16 x 40 channels x 4 B = 40 KB of LDS
+    a.OH = a.OW = a.IH = a.IW = 64
+    assert lib.madm_conv2d_can_post_groupnorm(ctypes.byref(a)) == 0          # 640 KB: the group does not fit
+    assert lib.madm_groupnorm_apply_cat(1, p, p, p, 64, 1, 1, 32, 32, 32, None, p, p, p, 1e-5, 0, None) == -1
 
 
 @pytest.fixture(scope="module")
