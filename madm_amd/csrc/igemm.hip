@@ -8,7 +8,9 @@
 // t+1 are issued before the MFMAs of tile t and written to the other buffer after them; one
 // barrier per K-tile.  The MFMA is issued as D = W_frag x A_frag so that every lane ends up with
 // 4 CONSECUTIVE output channels of one pixel: 8/16-byte stores, vector bias / residual loads.
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include "igemm_common.hpp"
 
 namespace {
@@ -730,19 +732,45 @@ inline bool is_halo_tile(int t) { return t == 4 || t == 5 || t == 9 || t == 10 |
 
 // Launch configurations measured on MI355X by tools/tune_insitu.py for the layer shapes of the SD-v1-4
 // feature extractor at bs=2, 512x512 (any other shape falls back to the heuristics below).
-// variant: 0 = plain, 1 = GroupNorm fused into the halo load, 2 = nearest-2x upsample gather
+// variant: 0 = plain, 1 = GroupNorm fused into the halo load, 2 = nearest-2x upsample gather, 3 = stride 2 (a downsample
+// conv shares M, N, K with a stride-1 conv of the next level: 8 x 8 x 1280 of the UNet; without a row of its own it takes
+// the plain row)
 struct Tuned { int dtype, M, N, K, KH, variant, tile, splitk; };
-inline int variant_of(const madm_conv2d_args* a) { return a->gn_sums1 ? 1 : (a->upsample ? 2 : 0); }
+inline int variant_of(const madm_conv2d_args* a) { return a->gn_sums1 ? 1 : (a->upsample ? 2 : (a->stride == 2 ? 3 : 0)); }
 const Tuned g_tuned[] = {
 #include "igemm_tuned.inc"
     {-1, 0, 0, 0, 0, 0, 0, 0}};
 
+// Run-time rows in front of the compiled-in table (A/B runs of tools/tune_concurrent.py without a rebuild): the file named
+// by MADM_TUNED_FILE holds one "dtype M N K KH variant tile splitk" row per line ('#' starts a comment); read once.
+const std::vector<Tuned>& tuned_overrides() {
+    static const std::vector<Tuned> rows = [] {
+        std::vector<Tuned> v;
+        const char* path = getenv("MADM_TUNED_FILE");
+        if (!path || !*path) return v;
+        FILE* f = fopen(path, "r");
+        if (!f) { fprintf(stderr, "madm: MADM_TUNED_FILE=%s cannot be opened\n", path); return v; }
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            Tuned t;
+            if (line[0] == '#') continue;
+            if (sscanf(line, "%d %d %d %d %d %d %d %d", &t.dtype, &t.M, &t.N, &t.K, &t.KH, &t.variant, &t.tile, &t.splitk) == 8)
+                v.push_back(t);
+        }
+        fclose(f);
+        return v;
+    }();
+    return rows;
+}
+
 const Tuned* find_tuned(int dtype, int M, int N, int K, int KH, int variant) {
     if (dtype == MADM_F16) dtype = MADM_BF16;   // same kernels, same instruction rate: the bf16 table serves both
     if (g_tile_override != 0) return nullptr;
+    for (const Tuned& t : tuned_overrides())
+        if (t.dtype == dtype && t.M == M && t.N == N && t.K == K && t.KH == KH && t.variant == variant) return &t;
     for (const Tuned* t = g_tuned; t->dtype >= 0; ++t)
         if (t->dtype == dtype && t->M == M && t->N == N && t->K == K && t->KH == KH && t->variant == variant) return t;
-    return nullptr;
+    return variant == 3 ? find_tuned(dtype, M, N, K, KH, 0) : nullptr;
 }
 
 int heuristic_tile(int M, int N, int K) {
@@ -944,12 +972,14 @@ int launch(const IgemmP& p0, int t, hipStream_t s, const PostGn& pn) {
         if ((p.N / pn.G) % 4 == 0) {
             auto kern = splitk_groupnorm_kernel<T, 4>;
             static std::atomic<uint64_t> attr_done{0};
-            if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done, "split-K + GroupNorm")) return e;
+            // the attribute is raised ONCE per device, so to the kernel's maximum, not to this launch's size (a later, larger
+            // group -- another resolution, train then eval in one process -- must still launch)
+            if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), PGN_MAX_LDS, attr_done, "split-K + GroupNorm")) return e;
             kern<<<pgrid, PGN_THREADS, lds, s>>>(p, pn);
         } else {
             auto kern = splitk_groupnorm_kernel<T, 2>;
             static std::atomic<uint64_t> attr_done{0};
-            if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, attr_done, "split-K + GroupNorm")) return e;
+            if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), PGN_MAX_LDS, attr_done, "split-K + GroupNorm")) return e;
             kern<<<pgrid, PGN_THREADS, lds, s>>>(p, pn);
         }
         rc = madm_check_launch("splitk_groupnorm_kernel");

@@ -1,0 +1,72 @@
+"""ORACLE (test infrastructure only): the reference's OWN arithmetic, emulated on the CPU.
+
+The reference never runs the path in fp32: training wraps the step in ``torch.cuda.amp.autocast()``
+(/root/reference/engine/train_loop.py:263,277), evaluation does the same (evaluation/evaluator.py:62-66,85), the VAE is
+loaded with ``torch_dtype=torch.float16`` and a frozen UNet too (modeling/meta_arch/ldm_diffusers.py:248,253-255).  This
+module restates what CUDA autocast does to the oracle modules' ops (ATen autocast_mode.cpp, fp16 policy lists) as a
+``TorchFunctionMode`` over CPU tensors that really carry the dtypes the GPU tensors would:
+
+* "lower precision" ops -- conv2d, linear, matmul / bmm, scaled_dot_product_attention: every floating tensor argument is
+  rounded to fp16, the product is accumulated in fp32 (what the matrix units do) and the result is rounded to fp16 once;
+  SDPA rounds the probabilities to fp16 before the PV product like a flash kernel;
+* "fp32" ops -- group_norm, layer_norm, softmax: arguments cast to fp32, fp32 result;
+* everything else (adds of the residual stream, SiLU, GELU, concat, nearest upsample) runs in the dtype type promotion
+  gives it, on fp16 tensors where the GPU would hold fp16 tensors.
+
+``half_parameters_`` rounds a module's parameters to fp16 values (kept in fp32 storage: the casts above reproduce the
+storage type where it matters), as ``from_pretrained(torch_dtype=float16)`` does.
+
+It answers one question (VERDICT r3 "What's weak" 2 / item 5): how far is the reference's own fp16-autocast arithmetic
+from the fp32 oracle on the metric's path -- the yardstick for the HIP f16 mode's 1.7e-3 .. 3.5e-3.  tools/precision_autocast.py
+runs it; tests/test_oracle.py pins it on the 64 x 64 case.
+"""
+import torch
+import torch.nn.functional as F
+from torch.overrides import TorchFunctionMode
+
+_LOW = torch.float16
+
+
+def _h(t):
+    return t.to(_LOW) if torch.is_tensor(t) and t.is_floating_point() else t
+
+
+def _f(t):
+    return t.float() if torch.is_tensor(t) and t.is_floating_point() else t
+
+
+def _sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, **kw):
+    assert attn_mask is None and dropout_p == 0.0 and not is_causal
+    q, k, v = _h(q).float(), _h(k).float(), _h(v).float()
+    scale = q.shape[-1] ** -0.5 if scale is None else scale
+    p = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
+    return (p.to(_LOW).float() @ v).to(_LOW)
+
+
+class CudaAutocastF16(TorchFunctionMode):
+    """``with CudaAutocastF16(): module(x)`` -- see the module docstring."""
+
+    LOWER = {F.conv2d, torch.conv2d, F.linear, torch.matmul, torch.bmm, torch.Tensor.matmul, torch.Tensor.__matmul__,
+             torch.Tensor.bmm, torch.mm}
+    FP32 = {F.group_norm, torch.group_norm, F.layer_norm, torch.layer_norm, F.softmax, torch.softmax, torch.Tensor.softmax}
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is F.scaled_dot_product_attention:
+            return _sdpa(*args, **kwargs)
+        if func in self.LOWER:
+            a = [_h(x).float() if torch.is_tensor(x) and x.is_floating_point() else x for x in args]
+            kw = {k: (_h(x).float() if torch.is_tensor(x) and x.is_floating_point() else x) for k, x in kwargs.items()}
+            return func(*a, **kw).to(_LOW)
+        if func in self.FP32:
+            return func(*[_f(x) for x in args], **{k: _f(x) for k, x in kwargs.items()})
+        return func(*args, **kwargs)
+
+
+@torch.no_grad()
+def half_parameters_(module):
+    """Parameters and buffers rounded to fp16 VALUES (``torch_dtype=torch.float16`` of ldm_diffusers.py:248,253-255)."""
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.is_floating_point():
+            t.copy_(t.to(_LOW).float())
+    return module

@@ -469,6 +469,9 @@ POST_GN_CASES = [
     # name, B, Cin, H, W, Cout, splitk, tile (0 = table / heuristic), time row, expected "applied"
     ("unet16_1280", 2, 64, 16, 16, 1280, 4, 0, True, True),       # 40 KB of LDS per group
     ("unet32_640", 2, 192, 32, 32, 640, 3, 0, True, True),        # 80 KB; halo kernel, three channel chunks in 16-bit modes
+    # 92 KB AFTER the 80 KB launch in the same process: the dynamic-LDS attribute is raised once per device and must
+    # cover the kernel's maximum, not the first launch's size (a 24 x 24 map of a 768-px eval image)
+    ("unet24_1280_after_80kb", 1, 64, 24, 24, 1280, 4, 0, False, True),
     ("unet8_1280_halo", 1, 128, 8, 8, 1280, 2, 9, False, True),   # the halo kernel's split-K (whole channel chunks)
     ("ragged_map", 3, 64, 5, 7, 128, 5, 3, True, True),
     ("ten_channel_groups", 2, 64, 8, 8, 320, 9, 3, True, True),   # 8-byte units (the 16-byte path needs N / groups % 4 == 0)

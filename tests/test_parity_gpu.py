@@ -186,6 +186,50 @@ def test_staged_pipeline_matches_forward(extractor):
         for a, b in zip(feats, want):
             assert torch.equal(a, b), f"step {step}: staged pipeline differs from forward()"
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_staged_pipeline_matches_forward_at_512(extractor, dtype):
+    """The TIMED launch path at the metric's size (BASELINE configs[1]: 2 x 3 x 512 x 512): four graphs of full-chip
+    kernels running side by side -- the 16 x 16 halo conv of one batch's VAE encoder next to other batches' GEMM / attention
+    / packed-f32 stem and LayerNorm kernels, two workgroups of different kernels per CU.  Every slot of every round must be
+    bit-identical to LdmRocm.forward on the same batch (a co-residency-triggered miscompute would show
+    here).  The submits are NOT separated by host syncs, so the batches really overlap; outputs are copied out on the
+    slot's own stream behind its UNet."""
+    from madm_amd.pipeline import StagedExtractor
+    case = dict(CASES["full_t0"])
+    images, cond_inputs, cond_emb, _, _ = make_inputs(**case)
+    m = extractor
+    m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = dtype
+    inputs = {"img": images.repeat(2, 1, 1, 1).cuda(), "cond_inputs": cond_inputs.repeat(2, 1, 1).cuda(),
+              "cond_emb": cond_emb.repeat(2, 1, 1).cuda()}
+    assert tuple(inputs["img"].shape) == (2, 3, 512, 512)
+    with torch.no_grad():
+        want = [f.clone() for f in m(inputs, "rgb")]
+        torch.cuda.synchronize()
+        keep = m.check_input_range
+        m.check_input_range = False
+        try:
+            pipe = StagedExtractor(m, inputs, unet_streams=3)
+            pipe.fork()
+            got = []
+            for step in range(12):                      # every slot comes round four times, 4 batches in flight
+                outs, done = pipe.submit()
+                s = pipe.s_unet[step % pipe.k]
+                with torch.cuda.stream(s):              # behind this slot's UNet, before the slot's next encoder may start
+                    got.append([f.clone() for f in outs])
+                    pipe.done[step % pipe.k].record(s)
+            pipe.join()
+            torch.cuda.synchronize()
+        finally:
+            m.check_input_range = keep
+    bad = []
+    for step, feats in enumerate(got):
+        assert len(feats) == len(want)
+        for i, (a, b) in enumerate(zip(feats, want)):
+            if not torch.equal(a, b):
+                bad.append((step, i, int((a != b).sum()), float((a.float() - b.float()).abs().max())))
+    assert not bad, f"staged pipeline differs from forward() at 512x512 (step, tap, elements, max diff): {bad[:8]}"
+
+
 def test_helper_functions_match_reference_signatures(extractor):
     """vae_encoder / add_noise / diffusion_unet keep the reference's call signatures
     (ldm_diffusers.py:283,349,454) and reproduce the golden intermediates when chained by hand."""

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""How far is the REFERENCE'S OWN arithmetic (fp16 CUDA autocast, fp16 VAE / frozen-UNet weights: engine/train_loop.py:277,
+evaluation/evaluator.py:62-66, ldm_diffusers.py:248,253-255) from the fp32 oracle on the metric's path?  CPU only: the fp32
+oracle and its autocast emulation (oracle/autocast_emul.py) on the same seeded inputs and weights; per-tensor relative L2
+and max-relative error.  The HIP f16 mode's figures against the same fp32 oracle are in profiles/round*_precision_f16_bf16.txt.
+    python tools/precision_autocast.py [--case full_t0|small_t0|small_t60|rect_t0] [--unet-weights f32|f16]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def run(case_name, unet_weights="f16", threads=None, f32_schedule=False):
+    from golden_util import CASES, make_inputs
+    from madm_amd import weights
+    from oracle import sd_modules, ldm_path
+    from oracle.autocast_emul import CudaAutocastF16, half_parameters_
+    if threads:
+        torch.set_num_threads(threads)
+    case = CASES[case_name]
+    images, cond, cond_emb, timesteps, noise = make_inputs(**case)
+    vae = weights.synth_init_(sd_modules.AutoencoderKL().eval(), 0, "vae.")
+    unet = weights.synth_init_(sd_modules.UNet2DConditionModel().eval(), 0, "unet.")
+    sched = sd_modules.DDPMScheduler()
+    t0 = time.time()
+    with torch.no_grad():
+        ref = ldm_path.ldm_forward(vae, unet, sched, noise, images, cond, cond_emb, timesteps=timesteps)
+    t_ref = time.time() - t0
+    half_parameters_(vae)                       # torch_dtype=torch.float16 (ldm_diffusers.py:248)
+    if unet_weights == "f16":
+        half_parameters_(unet)                  # frozen UNet: torch.float16 (:253); 'f32' = the fine-tuned UNet under autocast
+    if f32_schedule:
+        # diffusers' add_noise casts alphas_cumprod to the latents' dtype (oracle/sd_modules.py DDPMScheduler.add_noise, the
+        # restated diffusers 0.25 code): with fp16 latents sqrt(1 - fp16(0.99915)) = 0.03125 instead of 0.02915 at t = 0.
+        # This switch keeps the latents fp32 through add_noise to show the rest of the arithmetic on its own.
+        class _S:
+            def add_noise(self, x, n, t):
+                return sched.add_noise(x.float(), n, t)
+        sched_emu = _S()
+    else:
+        sched_emu = sched
+    t0 = time.time()
+    with torch.no_grad(), CudaAutocastF16():
+        emu = ldm_path.ldm_forward(vae, unet, sched_emu, noise, images, cond, cond_emb, timesteps=timesteps)
+    t_emu = time.time() - t0
+    rows = []
+    pairs = [("latents", emu["latents"], ref["latents"]), ("sample", emu["sample"], ref["sample"])]
+    pairs += [(f"tap{i}", a, b) for i, (a, b) in enumerate(zip(emu["unet_features"], ref["unet_features"]))]
+    for name, a, b in pairs:
+        a, b = a.float(), b.float()
+        rows.append((name, tuple(b.shape), float((a - b).norm() / b.norm()), float((a - b).abs().max() / b.abs().max())))
+    return rows, t_ref, t_emu
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="full_t0")
+    ap.add_argument("--unet-weights", default="f16", choices=["f16", "f32"])
+    args = ap.parse_args()
+    for f32_schedule in (False, True):
+        rows, t_ref, t_emu = run(args.case, args.unet_weights, f32_schedule=f32_schedule)
+        print(f"case {args.case}: fp32 oracle {t_ref:.1f} s, fp16-autocast emulation {t_emu:.1f} s on {torch.get_num_threads()} threads; "
+              f"VAE weights f16, UNet weights {args.unet_weights}; add_noise coefficients "
+              + ("in fp32 (NOT what the reference does: isolates the rest)" if f32_schedule else
+                 "in the latents' fp16 as diffusers computes them (the reference's behaviour)"))
+        print(f"{'tensor':10s} {'shape':22s} {'rel L2':>10s} {'max rel':>10s}   (emulated reference arithmetic vs fp32 oracle)")
+        for name, shape, l2, mx in rows:
+            print(f"{name:10s} {str(shape):22s} {l2:10.3e} {mx:10.3e}")
+
+
+if __name__ == "__main__":
+    main()
