@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MADM_ABI_VERSION 3
+#define MADM_ABI_VERSION 4
 
 typedef enum {
     MADM_OK = 0,
@@ -61,6 +61,12 @@ typedef enum {
 
 int madm_abi_version(void);
 const char* madm_last_error(void);
+
+/* Calibration loop (ABI 4; no reference counterpart: measurement infrastructure of bench.py's "calib" object): `blocks`
+ * workgroups of four waves issue `iters` x 8 independent v_mfma_f32_16x16x32_f16 each, operands in registers.  *flop (host,
+ * optional) receives the FLOP of the launch; time it with events on `stream`: 512 blocks on MI355X = two waves per SIMD on
+ * every CU, the rate this DEVICE sustains under a chip-wide MFMA load.  sink: 4 bytes of device memory, never written. */
+int madm_calib_mfma_loop(int iters, int blocks, float* sink, double* flop, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * madm_conv2d_fwd: implicit-GEMM convolution / linear layer on MFMA.

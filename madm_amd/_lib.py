@@ -103,6 +103,7 @@ class AttentionBwdArgs(ctypes.Structure):
 SYMBOLS = [
     ("madm_abi_version", c_int, []),
     ("madm_last_error", ctypes.c_char_p, []),
+    ("madm_calib_mfma_loop", c_int, [c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double), c_void_p]),
     ("madm_conv2d_workspace_bytes", c_size_t, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_suggest_splitk", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_pick_tile", c_int, [ctypes.POINTER(Conv2dArgs)]),

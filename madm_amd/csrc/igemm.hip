@@ -334,7 +334,7 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() { GLDS_ASM("s_wa
 // the gather needs no pixel arithmetic -- neither in the set-up (two integer divisions per staged row) nor per DMA
 // instruction (the address is row * ld + channel offset).
 template <typename T, int BM, int BN, int NS, bool LIN>
-__global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_kernel(const IgemmP p) {
+__global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? (NS == 2 ? 2 : 1) : (NS == 3 && BM == 64 ? 3 : 2)) void igemm_glds_kernel(const IgemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS address-space casts and gfx asm: device pass only (the host needs the stub)
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;
@@ -342,7 +342,9 @@ __global__ __launch_bounds__(256, NS == 3 && BM == 64 ? 3 : 2) void igemm_glds_k
     constexpr int ROWS = BM + BN;
     constexpr int LPT = ROWS / 32;          // wave instructions (8 rows each) per wave and K-tile
     constexpr int TILE_U4 = ROWS * 8;
-    static_assert(NS >= 3 && NS <= 4 && ROWS % 32 == 0, "ring depth / tile shape");
+    // NS = 2: the load of tile t + 1 is issued behind the barrier of step t and must have landed at step t + 1 (vmcnt(0)):
+    // it overlaps this block's MFMAs of tile t only -- for tiles whose two resident blocks cover each other (128 x 128)
+    static_assert(NS >= 2 && NS <= 4 && ROWS % 32 == 0, "ring depth / tile shape");
     extern __shared__ __attribute__((aligned(16))) uint4 gsmem[];   // [NS][ROWS][8 x 16 B]
     typedef __attribute__((address_space(3))) char lds_char;
 
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(PGN_THREADS) void splitk_groupnorm_kernel(const Ige
 inline size_t post_gn_lds(int HW, int N, int G) { return (size_t)HW * (size_t)(N / G) * sizeof(float); }
 
 int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
-inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8) || t == 11; }
+inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8) || t == 11 || t == 14 || t == 15; }
 // tile 13 (igemm_apanel.hip): plain linear layer, one source, whole rows resident: no split-K, no residual / time row /
 // fused output statistics (its epilogue touches no global memory but the stores)
 inline bool apanel_eligible(const madm_conv2d_args* a) {
@@ -799,7 +801,10 @@ bool halo_eligible(const madm_conv2d_args* a) {
 // 6 = igemm 64x64 with an 8-deep register prefetch (latency-bound small-M GEMMs streaming cold weights),
 // 7 / 8 = LDS-DMA igemm 64x64 (4-slot ring) / 128x64 (3-slot ring), 9 / 10 = halo BN=128 / BN=64 with LDS-DMA weights,
 // 11 = LDS-DMA igemm 64x64 with a 3-slot ring (48 KB: three blocks per CU, for grids of 513 .. 768 tiles),
-// 12 = halo conv3x3 on 16 x 16-pixel patches, BN = 128, halo and weights by LDS-DMA (conv3x3_h16.hip; maps >= 16 x 16)
+// 12 = halo conv3x3 on 16 x 16-pixel patches, BN = 128, halo and weights by LDS-DMA (conv3x3_h16.hip; maps >= 16 x 16),
+// 14 / 15 = LDS-DMA igemm 128x128 with a 3-slot (96 KB, one block per CU) / 2-slot ring (64 KB, two blocks per CU): 8 KB of
+// operands per MFLOP through the CU's load path instead of 11 (128x64) / 31 (64x64) -- few, fat workgroups for launches
+// whose neighbours on the chip are other streams' kernels (tools/tune_concurrent.py)
 int pick_tile_raw(const madm_conv2d_args* a) {
     const int M = a->B * a->OH * a->OW, K = a->KH * a->KW * (a->C1 + a->C2);
     const bool halo_ok = halo_eligible(a);
@@ -853,7 +858,7 @@ int pick_tile(const madm_conv2d_args* a) {
 
 void tile_dims(int t, int& bm, int& bn) {
     if (t == 12) { bm = 256; bn = 128; }
-    else if (t == 1 || t == 4 || t == 9) { bm = 128; bn = 128; }
+    else if (t == 1 || t == 4 || t == 9 || t == 14 || t == 15) { bm = 128; bn = 128; }
     else if (t == 2 || t == 5 || t == 8 || t == 10) { bm = 128; bn = 64; }
     else { bm = 64; bn = 64; }
 }
@@ -961,6 +966,8 @@ int launch(const IgemmP& p0, int t, hipStream_t s, const PostGn& pn) {
         else if (t == 7) { if (int e = launch_glds<T, 64, 64, 4>(p, grid, s)) return e; }
         else if (t == 8) { if (int e = launch_glds<T, 128, 64, 3>(p, grid, s)) return e; }
         else if (t == 11) { if (int e = launch_glds<T, 64, 64, 3>(p, grid, s)) return e; }
+        else if (t == 14) { if (int e = launch_glds<T, 128, 128, 3>(p, grid, s)) return e; }
+        else if (t == 15) { if (int e = launch_glds<T, 128, 128, 2>(p, grid, s)) return e; }
         else if (lin) igemm_kernel<T, 64, 64, 4, true><<<grid, 256, 0, s>>>(p);
         else igemm_kernel<T, 64, 64, 4, false><<<grid, 256, 0, s>>>(p);
         rc = madm_check_launch("igemm_kernel");

@@ -82,10 +82,15 @@ template <> __device__ __forceinline__ void ap_store2<bf16_t>(__amdgpu_buffer_rs
 // columns into a private ring (with WM = 2 the two waves of a column half fetch the same rows: twice the weight bytes on
 // the load path, still half of what a 64 x 64 tile moves per FLOP, and no barrier in the loop).
 // Built WITHOUT packed-FP32 VALU ops (device pass only; see csrc/Makefile's note for what was observed with them).
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AP_PKCHECK)
 #define AP_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
 #else
 #define AP_NO_PACKED_F32
+#endif
+
+#ifdef AP_PKCHECK   // tools/exp/pkf32_check.py: the kernel WITH packed-FP32 ops, every normalised element re-derived by scalar
+                    // v_sub_f32 / v_mul_f32 from the same registers; mismatches are recorded (16 words each, first 60)
+__device__ unsigned g_ap_pk[1024];
 #endif
 
 template <typename T, int BM, int WM>
@@ -211,8 +216,33 @@ __global__ __launch_bounds__(256, 2) AP_NO_PACKED_F32 void igemm_apanel_kernel(c
                 if (pi < npieces) {
                     float f[EPC];
                     chunk_to_f32<T>(pc[u], f);
+#ifdef AP_PKCHECK
+                    float f0[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) f0[e] = f[e];
+#endif
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mean) * rstd;
+#ifdef AP_PKCHECK
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        float g;
+                        asm volatile("v_sub_f32 %0, %1, %2\n\ts_nop 1\n\tv_mul_f32 %0, %0, %3" : "=&v"(g) : "v"(f0[e]), "v"(mean), "v"(rstd));
+                        if (__builtin_bit_cast(unsigned, g) != __builtin_bit_cast(unsigned, f[e])) {
+                            const unsigned k = atomicAdd(&g_ap_pk[0], 1u);
+                            if (k < 60) {
+                                unsigned* r = g_ap_pk + 16 + k * 16;
+                                const unsigned long long ex = __builtin_amdgcn_read_exec();
+                                r[0] = blockIdx.x; r[1] = tid; r[2] = (unsigned)r0; r[3] = (unsigned)u; r[4] = (unsigned)e;
+                                r[5] = __builtin_bit_cast(unsigned, f0[e]); r[6] = __builtin_bit_cast(unsigned, mean);
+                                r[7] = __builtin_bit_cast(unsigned, rstd); r[8] = __builtin_bit_cast(unsigned, f[e]);
+                                r[9] = __builtin_bit_cast(unsigned, g); r[10] = (unsigned)ex; r[11] = (unsigned)(ex >> 32);
+                                r[12] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+                                r[13] = (unsigned)npieces; r[14] = (unsigned)BM; r[15] = 0xabcd0000u + (unsigned)EPC;
+                            }
+                        }
+                    }
+#endif
                     apsmem[((pi >> 3) * BM + r0) * 8 + (pi & 7)] = f32_to_chunk<T>(f);
                 }
             }
@@ -402,6 +432,17 @@ int launch_igemm_apanel(const IgemmP& p, hipStream_t s) {
     madm_set_error("igemm (A panel): K = %d does not fit the panel", p.K);
     return MADM_ERR_UNSUPPORTED;
 }
+
+#ifdef AP_PKCHECK
+extern "C" int madm_debug_read_ap_pkcheck(unsigned* host, int n, int reset) {
+    int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ap_pk), sizeof(unsigned) * n);
+    if (reset) {
+        static unsigned zeros[1024];
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ap_pk), zeros, sizeof(zeros));
+    }
+    return rc;
+}
+#endif
 
 #ifdef AP_STAMPS
 extern "C" int madm_debug_read_ap_stamps(unsigned long long* host, int n) {

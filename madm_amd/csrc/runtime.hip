@@ -23,7 +23,45 @@ int madm_check_launch(const char* what) {
     return MADM_OK;
 }
 
+namespace {
+// Calibration loop of bench.py ("calib" in its JSON line): nothing but independent v_mfma_f32_16x16x32_f16, operands in
+// registers, 8 accumulators per wave.  Two workgroups of four waves per CU (2 waves per SIMD, the residency of the conv
+// kernels) hold the matrix pipes busy; its rate is what THIS device sustains under a chip-wide MFMA load (devices of one
+// pool differ by up to 12 % there, MI355X_MICROARCH.md "DVFS give-back" item 5).
+typedef float calib_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 calib_f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void calib_mfma_loop_kernel(int iters, float* sink) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    calib_f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = calib_f32x4{0.f, 0.f, 0.f, 0.f};
+    calib_f16x8 a, b;
+    // varied operands: the clock the chip holds depends on the data (zeros read up to 20 % high)
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u;
+    for (int i = 0; i < 8; ++i) {
+        h = h * 1664525u + 1013904223u;
+        a[i] = (_Float16)(((int)(h >> 20) - 2048) * (1.0f / 2048.f));
+        h = h * 1664525u + 1013904223u;
+        b[i] = (_Float16)(((int)(h >> 20) - 2048) * (1.0f / 2048.f));
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678f) sink[0] = s;
+#endif
+}
+}  // namespace
+
 extern "C" {
 int madm_abi_version(void) { return MADM_ABI_VERSION; }
 const char* madm_last_error(void) { return g_err; }
+
+int madm_calib_mfma_loop(int iters, int blocks, float* sink, double* flop, void* stream) {
+    MADM_REQUIRE(iters > 0 && blocks > 0 && sink != nullptr, "calib: iters, blocks > 0 and a 4-byte device sink");
+    calib_mfma_loop_kernel<<<dim3((unsigned)blocks), 256, 0, (hipStream_t)stream>>>(iters, sink);
+    if (flop) *flop = 2.0 * 16 * 16 * 32 * 8.0 * 4.0 * (double)iters * (double)blocks;   // 8 MFMAs x 4 waves per iteration
+    return madm_check_launch("calib_mfma_loop_kernel");
+}
 }

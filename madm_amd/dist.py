@@ -88,6 +88,10 @@ class GradBucketReducer:
         self.g, self.dist, self.bucket = flat_grad, dist, int(bucket_numel)
         self.mode, self.wire_dtype = mode, wire_dtype
         self.world = 1 if dist is None else dist.get_world_size()
+        # MADM_FORCE_PROCESS_GROUP (the switch of ``init``): a single rank still runs every collective (identity sums), so the
+        # RCCL code path -- stream-ordered reduce-scatter + all-gather, 16-bit wire -- executes on a one-GPU box
+        # (tests/test_train_gpu.py::test_trainer_step_through_rccl_single_rank)
+        self.active = dist is not None and (self.world > 1 or bool(os.environ.get("MADM_FORCE_PROCESS_GROUP")))
         self.handles = []
         self._wire = []          # (lo, hi, 16-bit buffer) of the buckets in flight
         self._shards = []        # keeps the reduce-scatter outputs alive until finish()
@@ -114,7 +118,7 @@ class GradBucketReducer:
 
     def reduce_range(self, lo, hi):
         """Starts the reduction of g[lo:hi] in bucket-sized pieces (async)."""
-        if self.dist is None or self.world == 1:
+        if not self.active:
             return
         for a in range(lo, hi, self.bucket):
             b = min(a + self.bucket, hi)
@@ -143,9 +147,10 @@ class GradBucketReducer:
         self.handles = []
         self._shards = []
         self.done_lo = self.g.numel()
-        if self.world > 1:
+        if self.active:
             if self.wire_dtype is None:
-                self.g.mul_(1.0 / self.world)
+                if self.world > 1:
+                    self.g.mul_(1.0 / self.world)
             else:
                 for a, b, w in self._wire:
                     self.g[a:b].copy_(w)

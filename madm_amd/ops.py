@@ -55,7 +55,8 @@ PROFILE = None
 PROFILE_DIFF = False
 _TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64", 4: "conv3x3_halo_x128", 5: "conv3x3_halo_x64",
                6: "igemm_64x64d", 7: "igemm_glds_64x64", 8: "igemm_glds_128x64", 9: "conv3x3_halo_dma_x128",
-               10: "conv3x3_halo_dma_x64", 11: "igemm_glds_64x64s", 12: "conv3x3_h16_x128", 13: "igemm_apanel"}
+               10: "conv3x3_halo_dma_x64", 11: "igemm_glds_64x64s", 12: "conv3x3_h16_x128", 13: "igemm_apanel",
+               14: "igemm_glds_128x128", 15: "igemm_glds_128x128d"}
 EXP_NO_STATS = bool(int(__import__('os').environ.get('MADM_EXP_NO_STATS', '0')))   # timing experiment only
 FORCE_SPLITK = None   # tools/tune_insitu.py: split-K factor forced on every small-M launch
 if os.environ.get("MADM_EXP_SPLITK"):   # experiment: e.g. 1 = no split-K anywhere (does the staged pipeline still want it?)
@@ -63,6 +64,13 @@ if os.environ.get("MADM_EXP_SPLITK"):   # experiment: e.g. 1 = no split-K anywhe
 # timing experiments only (results become garbage): launches of the named classes are skipped -- "layernorm", "gn_apply",
 # "attention", "softmax", or tile codes of madm_conv2d_pick_tile ("tile7", ...): what would the step cost without them?
 EXP_SKIP = set(filter(None, os.environ.get("MADM_EXP_SKIP", "").split(",")))
+_SKIP_RE = [__import__("re").compile(t[3:]) for t in EXP_SKIP if t.startswith("re:")]
+
+
+def _skip_match(desc):
+    return any(r.search(desc) for r in _SKIP_RE)
+
+
 FUSE_GN = True   # fold GroupNorm(+SiLU) into eligible 3x3 convs (debug switch)
 # the GroupNorm that consumes a split-K conv rides on its reduction (conv2d(post_gn=...)); env MADM_NO_POST_GN for A/B runs
 POST_GN = not bool(int(os.environ.get("MADM_NO_POST_GN", "0")))
@@ -221,8 +229,11 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         ws = _workspace(nbytes, x1.device)
         a.workspace = ws.data_ptr()
         a.workspace_bytes = ws.numel()
-    if EXP_SKIP and ("tile%d" % lib.madm_conv2d_pick_tile(ctypes.byref(a))) in EXP_SKIP:
-        return out if post_gn is None else (out, applied)
+    if EXP_SKIP:
+        # timing experiments only (tools/exp/skip_sensitivity.sh): "tileN", or "re:<regex>" on "k<KH> s<stride> M.. N.. K.."
+        if ("tile%d" % lib.madm_conv2d_pick_tile(ctypes.byref(a))) in EXP_SKIP or _skip_match(
+                f"k{KH} s{stride}{' up' if upsample else ''} M{M} N{N} K{KH * KW * (C1 + C2)}"):
+            return out if post_gn is None else (out, applied)
     if PROFILE is None:
         check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     else:
@@ -626,7 +637,7 @@ def attention(q, k, v, B, H, Lq, Lk, D, scale, out=None):
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
     a.B, a.H, a.Lq, a.Lk, a.D = B, H, Lq, Lk, D
     a.scale = float(scale)
-    if "attention" in EXP_SKIP:
+    if "attention" in EXP_SKIP or (EXP_SKIP and _skip_match(f"attn d{D} Lq{Lq} Lk{Lk}")):
         return out
     with _Prof(f"attn_d{D}" + _SUFFIX[q.dtype], 4.0 * B * H * Lq * Lk * D,
                f"B{B} H{H} Lq{Lq} Lk{Lk}"):

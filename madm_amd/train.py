@@ -49,10 +49,10 @@ class MadmTrainer:
         self._final = [False] * len(self.opt.flat.params)
         self._ptr = len(self._final) - 1
         self._pend_dst, self._pend_src, self._pend_ids = [], [], set()
-        self.overlap = dist is not None and dist.get_world_size() > 1
+        self.overlap = self.reducer.active     # world > 1 (or a forced single rank: dist.GradBucketReducer.active)
         model.grad_sink = self
         self.reduced_during_backward = 0       # elements whose all-reduce started before the backward returned
-        if dist is not None and dist.get_world_size() > 1:
+        if self.reducer.active:
             dist.broadcast(self.opt.flat.flat, src=0)
             torch.autograd.graph.increment_version(self.opt.flat.params)
             # DDP's _sync_module_states covers EVERY parameter and buffer, frozen ones included: the EMA teacher

@@ -14,6 +14,12 @@ import zlib
 import torch
 
 
+# MADM_SYNTH_CACHE=1 (tests/conftest.py): the drawn values are kept per (seed, name, shape), so the ~40 model constructions
+# of a test session draw the 860 M synthetic parameters once (6.9 s per UNet on 8 cores otherwise); values are COPIED into
+# the parameters, the cache is never aliased.  ~3.8 GB of host memory per seed.
+_SYNTH_CACHE = {} if os.environ.get("MADM_SYNTH_CACHE") else None
+
+
 def _gen(seed, name):
     return torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
 
@@ -23,6 +29,10 @@ def synth_init_(module, seed=0, prefix=""):
     """Fills every parameter of ``module`` in place (on its current device) and returns it."""
     for name, p in module.named_parameters():
         full = prefix + name
+        key = (seed, full, tuple(p.shape))
+        if _SYNTH_CACHE is not None and key in _SYNTH_CACHE:
+            p.copy_(_SYNTH_CACHE[key].to(p.dtype))
+            continue
         g = _gen(seed, full)
         leaf = name.rsplit(".", 1)[-1]
         if leaf in ("prompt_embed", "time_embed"):          # trunc_normal_(std=0.02) in the reference (ldm_base.py:653,671)
@@ -36,6 +46,8 @@ def synth_init_(module, seed=0, prefix=""):
             v = 1.0 + 0.1 * torch.randn(p.shape, generator=g)
         else:
             v = 0.1 * torch.randn(p.shape, generator=g)
+        if _SYNTH_CACHE is not None:
+            _SYNTH_CACHE[key] = v
         p.copy_(v.to(p.dtype))
     return module
 

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("MADM_SYNTH_CACHE", "1")   # madm_amd/weights.py: draw the seeded synthetic parameters once per session
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.lib.madm_abi_version() == 3
+    assert _lib.lib.madm_abi_version() == 4
 
 
 def test_struct_layout_matches_header_field_order():

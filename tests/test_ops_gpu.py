@@ -62,6 +62,16 @@ CONV_CASES = [
     ("glds128_asym_s2", 2, [64], 16, 16, 128, 3, 2, "asym", False, 8, 1),
     ("glds128_1x1_longk_splitk", 2, [640], 8, 8, 640, 1, 1, "none", False, 8, 2),
     ("glds128_tiny_cout", 2, [64], 8, 8, 4, 3, 1, "same", False, 8, 1),
+    # 14 / 15 = LDS-DMA igemm 128 x 128 (3-slot ring, one block per CU / 2-slot ring, two blocks per CU): ragged M and N,
+    # K shorter and longer than the ring, gathers with padding, concat + stride 2, upsample, split-K
+    ("glds128sq_1x1_longk", 2, [1280], 8, 16, 320, 1, 1, "none", False, 14, 1),
+    ("glds128sq_3x3_ragged", 1, [64], 13, 21, 192, 3, 1, "same", False, 14, 1),
+    ("glds128sq_concat_s2_splitk", 2, [128, 64], 16, 16, 192, 3, 2, "same", False, 14, 2),
+    ("glds128sq_onetile", 2, [64], 8, 8, 64, 1, 1, "none", False, 14, 1),
+    ("glds128sq2_1x1_longk", 2, [1280], 8, 16, 320, 1, 1, "none", False, 15, 1),
+    ("glds128sq2_3x3_ragged", 1, [64], 13, 21, 192, 3, 1, "same", False, 15, 1),
+    ("glds128sq2_upsample_splitk", 2, [128], 6, 6, 64, 3, 1, "same", True, 15, 3),
+    ("glds128sq2_onetile", 2, [64], 8, 8, 64, 1, 1, "none", False, 15, 1),
     ("glds64s_1x1", 2, [320], 8, 8, 320, 1, 1, "none", False, 11, 1),
     ("glds64s_ragged_3x3_splitk", 2, [128], 5, 7, 192, 3, 1, "same", False, 11, 2),
     # 9 / 10 = halo conv with LDS-DMA weights (three-slot ring, single halo buffer)
@@ -240,6 +250,10 @@ LN_FOLD_CASES = [
     ("geglu_glds128", 256, 320, 2560, 8, True, False),
     ("geglu_reg128x64", 200, 640, 1024, 2, True, False),
     ("reg128x128", 256, 320, 256, 1, False, False),
+    ("glds128sq_qkv", 300, 320, 960, 14, False, False),
+    ("glds128sq_geglu", 256, 640, 1024, 14, True, False),
+    ("glds128sq2_q_res", 200, 1280, 640, 15, False, True),
+    ("glds128sq2_fullchip_geglu", 8192, 320, 2560, 15, True, False),
     ("reg64x64", 96, 64, 128, 3, False, True),
     ("reg64x64d", 70, 128, 64, 6, False, False),
     # tile 13 = A-stationary kernel (igemm_apanel.hip): resident row panel (BM = 128 / 64 / 32 by K), LayerNorm in place

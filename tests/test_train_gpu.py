@@ -486,3 +486,67 @@ def test_table_adamw_matches_torch_adamw_with_groups(cuda):
         for n, p in params.items():
             e = (p.detach() - rnames[n].detach()).abs().max().item()
             assert e < 2e-6, f"step {step} {n}: {e:.2e}"
+
+
+def test_trainer_step_through_rccl_single_rank(cuda, monkeypatch):
+    """The exchange step of the training path through RCCL itself (backend "nccl"; until round 3 only gloo had executed it):
+    a forced world-1 process group (MADM_FORCE_PROCESS_GROUP -> dist.GradBucketReducer.active) runs the start-up broadcasts,
+    the bucketed reduce-scatter + all-gather overlapped with the backward on RCCL's stream, and the 16-bit wire.  With one
+    rank every sum is the identity, so after one MadmTrainer.run_step the parameters must equal those of the same step
+    without a process group -- bit for bit on the fp32 wire, to bf16 rounding of the gradients on the bf16 wire
+    (engine/train_loop.py:277-302 + DDP, config_files/common/train.py:12-13)."""
+    import copy
+    import torch.distributed as tdist
+    from madm_amd import dist as mdist
+    from madm_amd.train import MadmTrainer
+    if tdist.is_initialized():
+        pytest.skip("a default process group already exists in this process")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    model = build_product_train(torch.float32, "train_depth_lora_only")
+    sc = train_dropout_scales(TRAIN_CASE["B"])
+    model.sem_seg_head.dropout_scale_override = [sc[0], sc[1], sc[0], sc[1]]
+    model.ema_sem_seg_head.dropout_scale_override = [sc[2], sc[2]]
+    state0 = copy.deepcopy({n: p.detach().clone() for n, p in model.named_parameters()})
+    bufs0 = {n: b.detach().clone() for n, b in model.named_buffers()}
+
+    def one_step(dist, **kw):
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                p.copy_(state0[n])
+            for n, b in model.named_buffers():
+                b.copy_(bufs0[n])
+        torch.autograd.graph.increment_version(list(model.parameters()))
+        model.train_iter_index = 0           # (EMA update and the teacher's timestep depend on it)
+        trainer = MadmTrainer(model, lr=1e-3, weight_decay=0.05, grad_clip=0.01, amp=False, dist=dist, **kw)
+        random.seed(TRAIN_CASE["py_seed"])
+        np.random.seed(TRAIN_CASE["np_seed"])
+        losses, norm, stepped = trainer.run_step(train_inputs(**TRAIN_CASE))
+        torch.cuda.synchronize()
+        assert stepped
+        return losses, norm, {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}, trainer
+
+    base_l, base_n, base_p, _ = one_step(None)
+    monkeypatch.setenv("MADM_FORCE_PROCESS_GROUP", "1")
+    d = mdist.init("nccl", torch.device("cuda", torch.cuda.current_device()))
+    assert d is not None and d.get_backend() == "nccl" and d.get_world_size() == 1
+    try:
+        for kw, exact in ((dict(exchange="rs_ag"), True), (dict(exchange="allreduce"), True),
+                          (dict(exchange="rs_ag", wire_dtype=torch.bfloat16), False)):
+            l, nrm, p, tr = one_step(d, **kw)
+            assert tr.reducer.active and tr.reducer._stream_ordered and tr.overlap
+            assert tr.last_allreduce_exposed_ms is not None and tr.last_overlap_frac is not None
+            for k in base_l:
+                assert l[k] == base_l[k], (kw, k)                         # the forward does not depend on the exchange
+            if exact:
+                # identity collectives: the same gradients up to the run-to-run summation order of the weight-gradient
+                # kernel's f32 atomics (two no-dist steps differ by as much)
+                assert abs(nrm - base_n) <= 1e-6 * base_n, (kw, nrm, base_n)
+                for n in base_p:
+                    assert torch.allclose(p[n], base_p[n], rtol=1e-5, atol=1e-6), (kw, n)
+            else:
+                assert abs(nrm - base_n) <= 1e-2 * base_n
+                worst = max(float((p[n] - base_p[n]).abs().max() / (base_p[n].abs().max() + 1e-12)) for n in base_p)
+                assert worst < 2e-2, worst                                # AdamW's first step: lr * sign-like update
+    finally:
+        d.destroy_process_group()

@@ -19,8 +19,8 @@ import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-LIN_TILES = [1, 2, 3, 7, 8, 11, 13]
-CONV_TILES = [2, 7, 8, 9, 10, 11, 12]
+LIN_TILES = [1, 2, 3, 7, 8, 11, 14, 15]
+CONV_TILES = [2, 7, 8, 9, 10, 11, 12, 14, 15]
 SPLITS = [1, 2, 3, 4, 6, 8, 12, 24]
 
 
