@@ -220,6 +220,9 @@ __global__ __launch_bounds__(256, 2) AP_NO_PACKED_F32 void igemm_apanel_kernel(c
                     float f0[EPC];
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) f0[e] = f[e];
+#ifdef AP_PKNOP     // experiment: wait states between the EXEC write that opens this branch and the first packed op
+                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
 #endif
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) f[e] = (f[e] - mean) * rstd;

@@ -21,6 +21,9 @@ from ._lib import EPI_GEGLU
 LORA_PAD = 64  # K-extension of a LoRA-augmented GEMM (>= sum of the fused ranks), one bf16 K-tile
 
 
+# The transformer block's last linear layer (ff.net[2] + residual) composed with Transformer2DModel.proj_out (+ residual): one
+# two-source GEMM [h2 | g] [Wp | Wp Wf]^T instead of two launches (16 per UNet forward); MADM_NO_FUSE_PROJ_OUT=1 for A/B runs
+FUSE_PROJ_OUT = not bool(int(os.environ.get("MADM_NO_FUSE_PROJ_OUT", "0")))
 FOLD_LN = not bool(int(os.environ.get("MADM_NO_FOLD_LN", "0")))   # LayerNorm folded into its consumer GEMM (A/B switch)
 
 
@@ -241,7 +244,7 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.ff = FeedForward(dim)
 
-    def forward(self, h, B, L, ctx, Lk):
+    def forward(self, h, B, L, ctx, Lk, defer_ff_out=False):
         """The three LayerNorms are folded into the GEMMs that consume them (QKV, cross-attention Q, GEGLU projection:
         FOLD_LN) -- 48 launches per UNet forward less; with an active LoRA adapter on a consuming projection the norm runs
         as its own pass (the adapter's skinny GEMM reads the normalised rows)."""
@@ -252,6 +255,8 @@ class BasicTransformerBlock(nn.Module):
         f2 = FOLD_LN and not a2._fused("_f_q", ("to_q",)).has_active_lora()
         h = a2(h if f2 else self.norm2(h), B, L, ctx=ctx.t if isinstance(ctx, CtxKV) else ctx, Lk=Lk, residual=h, kv=kv,
                ln=self.norm2 if f2 else None)
+        if defer_ff_out:    # Transformer2DModel folds ff.net[2] into its proj_out: hand back the stream and the GEGLU output
+            return h, self.ff.net[0](h if FOLD_LN else self.norm3(h), ln=self.norm3 if FOLD_LN else None)
         h = self.ff(h if FOLD_LN else self.norm3(h), residual=h, ln=self.norm3 if FOLD_LN else None)
         return h
 
@@ -265,12 +270,48 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
         self.proj_out = Conv2d(inner, in_channels, 1)
 
+    def _proj_out_ff_operand(self, dtype):
+        """[Wp | Wp Wf] (two gather sources: the residual stream h2 and the GEGLU output g) and Wp bf + bp: the block's last
+        linear layer (ff.net[2], h3 = h2 + Wf g + bf) composed with proj_out (out = Wp h3 + bp + x) -- the same 5 C^2
+        multiply-adds per token in ONE launch, h3 is never stored.  Composed in f64 from the f32 masters, rounded once."""
+        ff2, po = self.transformer_blocks[0].ff.net[2], self.proj_out
+        ver = tuple((p._version, p.data_ptr()) for p in (ff2.weight, ff2.bias, po.weight, po.bias))
+        cache = self.__dict__.setdefault("_po_cache", {})
+        hit = cache.get(dtype)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            wp64 = po.weight.detach().double().flatten(1)                      # [C, C]
+            wf64 = ff2.weight.detach().double()                                # [C, 4C]
+            w = torch.cat([wp64, wp64 @ wf64], dim=1).float()                  # [C, C + 4C]
+            b = (wp64 @ ff2.bias.detach().double() + po.bias.detach().double()).float().contiguous()
+            C = wp64.shape[0]
+            packed = packing.pack_conv_weight(w[:, :, None, None].contiguous(), dtype, ops.k_tile(dtype), [C, 4 * C])
+        cache[dtype] = (ver, (packed, b))
+        return packed, b
+
     def forward(self, x, ctx, Lk):
         h = self.proj_in(self.norm(x), stats=False)
         t = h.t
+        if FUSE_PROJ_OUT and len(self.transformer_blocks) == 1 and self.proj_out.n_pad == self.proj_out.out_channels:
+            h2, g = self.transformer_blocks[0](t, x.B, x.HW, ctx, Lk, defer_ff_out=True)
+            wp, b = self._proj_out_ff_operand(h2.dtype)
+            C = self.proj_out.out_channels
+            st = None if ops.EXP_NO_STATS else ops.new_chsums(x.B, C, h2.device)
+            o = ops.conv2d(h2, wp, x.B, x.H, x.W, N=C, x2=g, bias=b, residual=x.t, stats=st, alg_nk=(C, 5 * h2.shape[1]))
+            return Tok(o, x.B, x.H, x.W, st)
         for blk in self.transformer_blocks:
             t = blk(t, x.B, x.HW, ctx, Lk)
         return self.proj_out(x.like(t), residual=x)
+
+    def __deepcopy__(self, memo):       # the composed operand is derived data (EMA copies must not share or keep it)
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_po_cache":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
 
 # ----------------------------------------------------------------------------- resnet & samplers

@@ -518,6 +518,8 @@ def test_trainer_step_through_rccl_single_rank(cuda, monkeypatch):
                 b.copy_(bufs0[n])
         torch.autograd.graph.increment_version(list(model.parameters()))
         model.train_iter_index = 0           # (EMA update and the teacher's timestep depend on it)
+        model.sem_seg_head.dropout_scale_override = [sc[0], sc[1], sc[0], sc[1]]      # consumed by every step
+        model.ema_sem_seg_head.dropout_scale_override = [sc[2], sc[2]]
         trainer = MadmTrainer(model, lr=1e-3, weight_decay=0.05, grad_clip=0.01, amp=False, dist=dist, **kw)
         random.seed(TRAIN_CASE["py_seed"])
         np.random.seed(TRAIN_CASE["np_seed"])

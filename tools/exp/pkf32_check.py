@@ -52,6 +52,7 @@ def main():
         lib.madm_debug_set_conv_tile(13)
         bad_tot, mism_tot = 0, 0
         first = None
+        hist = {}
         try:
             for rep in range(args.reps):
                 out = ops.linear(xd, wd, bias=bd, ln=(cd, 1e-5))
@@ -62,11 +63,17 @@ def main():
                 if has:
                     raw.madm_debug_read_ap_pkcheck(buf, 1024, 1)
                     mism_tot += buf[0]
+                    recs = [list(buf[16 + 16 * k: 32 + 16 * k]) for k in range(min(buf[0], 60))]
+                    for r in recs:      # (element, 16-lane group, piece round, wave slot on its SIMD, active lanes of the mismatch)
+                        key = (r[4], (r[1] & 63) >> 4, r[3], r[12] & 15, f"{r[11]:08x}{r[10]:08x}")
+                        hist[key] = hist.get(key, 0) + 1
                     if buf[0] and first is None:
-                        first = [list(buf[16 + 16 * k: 32 + 16 * k]) for k in range(min(buf[0], 12))]
+                        first = recs[:4]
         finally:
             lib.madm_debug_set_conv_tile(0)
         print(f"M{M} K{C} N{N}: {args.reps} launches, wrong output elements {bad_tot}, in-kernel packed != scalar {mism_tot}")
+        for key, n in sorted(hist.items()):
+            print(f"   records: element {key[0]} lane group {key[1]} (lanes {16 * key[1]}..{16 * key[1] + 15}) piece round u={key[2]} wave slot {key[3]} mismatching lanes {key[4]}: {n}")
         for r in first or []:
             hw = r[12]
             print(f"   wg {r[0]:5d} tid {r[1]:3d} (lane {r[1] & 63:2d}, l16 {r[1] & 15:2d}) row {r[2]:3d} u {r[3]} e {r[4]}  x {f32(r[5]):9.5f} mean {f32(r[6]):9.5f} "
