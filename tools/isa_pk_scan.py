@@ -1,48 +1,87 @@
 #!/usr/bin/env python3
-"""Static scan of gfx950 ISA (hipcc -S --cuda-device-only) for the instruction pattern behind the packed-FP32 observation of
-DESIGN.md section 11.3: a packed FP32 VALU op that selects register halves (op_sel / op_sel_hi) issued as the FIRST vector
-instruction behind an EXEC write (s_and_saveexec / s_or_b64 exec / ... , or a block entry reached by such a branch).
-usage: isa_pk_scan.py file.s [...]   -> per kernel: sites, with the distance (instructions) to the EXEC write / label"""
+"""Static check of the SHIPPED gfx950 code for packed-FP32 VALU instructions.
+
+On MI355X a `v_pk_add_f32 ... op_sel:[0,1]` (the LOW result takes its operand from the HIGH register of the pair) delivered
+the low result with that operand read as 0 in lanes 48..63, intermittently, when a second wave on the SIMD was in an MFMA loop
+(instrumented kernel, tools/exp/pkf32_check.py).  The library is therefore built without packed-FP32 ops
+(csrc/Makefile: -target-feature -packed-fp32-ops); this script proves it on the binary:
+
+    isa_pk_scan.py <libmadm_hip.so | file.s ...>      exit status 1 when a packed-FP32 instruction is found
+
+For .so / .o inputs the gfx950 code objects are cut out of the clang offload bundle and disassembled with llvm-objdump."""
+import os
 import re
+import struct
+import subprocess
 import sys
+import tempfile
 
-EXECW = re.compile(r"^\s*(s_and_saveexec_b64|s_or_saveexec_b64|s_andn2_saveexec_b64|s_(or|and|andn2|xor|mov)_b64\s+exec)")
-PK = re.compile(r"^\s*v_pk_(add|mul|fma)_f32\b.*op_sel")
-LABEL = re.compile(r"^\.LBB\d+_\d+:")
-FUNC = re.compile(r"^(_Z\w+):")
-SKIP = re.compile(r"^\s*(;|\.|$)|^\s*;;#")
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+PK = re.compile(r"\bv_pk_(add|mul|fma)_f32\b")
+LOWSEL = re.compile(r"\bop_sel:\[[01,]*1[01,]*\]")      # a LOW result fed from a HIGH register
 
 
-def scan(path, window=1):
-    func, sites = None, []
-    hist = []       # last real instructions / labels
-    for ln in open(path):
-        m = FUNC.match(ln)
+def code_objects(path):
+    data = open(path, "rb").read()
+    magic, pos, out = b"__CLANG_OFFLOAD_BUNDLE__", 0, []
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            return out
+        nb = struct.unpack_from("<Q", data, i + 24)[0]
+        off = i + 32
+        for _ in range(nb):
+            o, sz, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl].decode(errors="replace")
+            off += tl
+            if "gfx950" in triple and sz:
+                out.append(data[i + o:i + o + sz])
+        pos = i + 24
+
+
+def disassemble(blob):
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(blob)
+        f.flush()
+        return subprocess.run([OBJDUMP, "-d", f.name], capture_output=True, text=True, check=True).stdout
+
+
+def scan_text(text):
+    """-> (packed-FP32 instructions, of them with a low-lane op_sel, {kernel: count})"""
+    func, total, low, per = "?", 0, 0, {}
+    for ln in text.splitlines():
+        m = re.match(r"^[0-9a-f]* ?<([^>]+)>:$", ln.strip()) or re.match(r"^(_Z\w+):", ln)
         if m:
             func = m.group(1)
-            hist = []
             continue
-        if LABEL.match(ln):
-            hist.append(("label", ln.strip()))
-            continue
-        if SKIP.match(ln):
-            continue
-        ins = ln.strip()
-        if PK.match(ln):
-            back = hist[-window:]
-            why = [k for k, _ in back if k in ("label", "execw")]
-            if why:
-                sites.append((func, ins, [t for _, t in back]))
-        hist.append(("execw" if EXECW.match(ln) else "ins", ins))
-    return sites
+        if PK.search(ln):
+            total += 1
+            per[func] = per.get(func, 0) + 1
+            if LOWSEL.search(ln):
+                low += 1
+    return total, low, per
 
 
-for p in sys.argv[1:]:
-    s = scan(p)
-    per = {}
-    for f, ins, back in s:
-        per.setdefault(f, []).append((ins, back))
-    print(f"{p}: {len(s)} packed-FP32 op_sel instructions directly behind an EXEC write or a block entry, in {len(per)} kernels")
-    for f, v in sorted(per.items(), key=lambda kv: -len(kv[1]))[:8]:
-        print(f"   {len(v):4d}  {f[:90]}")
-        print(f"         e.g. {v[0][1][-1]}  ->  {v[0][0]}")
+def scan(path):
+    if path.endswith(".s"):
+        return scan_text(open(path).read())
+    total, low, per = 0, 0, {}
+    for blob in code_objects(path):
+        t, l_, p = scan_text(disassemble(blob))
+        total += t
+        low += l_
+        for k, v in p.items():
+            per[k] = per.get(k, 0) + v
+    return total, low, per
+
+
+if __name__ == "__main__":
+    bad = 0
+    for p in sys.argv[1:]:
+        total, low, per = scan(p)
+        print(f"{p}: {total} packed-FP32 VALU instructions ({low} of them feed a LOW result from a HIGH register) in {len(per)} kernels")
+        for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:6]:
+            print(f"   {v:6d}  {k[:100]}")
+        bad += total
+    sys.exit(1 if bad else 0)

@@ -120,15 +120,22 @@ def main():
     ap.add_argument("--max-m", type=int, default=8192, help="largest M tuned (the VAE's 512^2 .. 128^2 maps lie above)")
     ap.add_argument("--rows", default="", help="write MADM_TUNED_FILE rows of the side-by-side winners here")
     ap.add_argument("--only", default="", help="regex on the shape description")
+    ap.add_argument("--workload", default="extract", choices=["extract", "eval"])
     args = ap.parse_args()
+    torch.set_grad_enabled(False)
     from madm_amd.ldm_rocm import LdmRocm
     from madm_amd import ops
     from madm_amd._lib import lib
     import bench
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
-    m = LdmRocm("", [], [5, 8, 11], [], input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
-                compute_dtype=dtype, weights='synthetic', seed=0)
-    call = (bench.make_inputs(args.batch, 512, torch.device("cuda")), "rgb")
+    if args.workload == "eval":      # BASELINE configs[2]: whole meta-arch inference forward, one image
+        args.batch = 1
+        m = bench.build_eval_model(dtype, torch.device("cuda"))
+        call = ([{"target_second_modality": 255.0 * torch.rand((3, 512, 512)).cuda()}],)
+    else:
+        m = LdmRocm("", [], [5, 8, 11], [], input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
+                    compute_dtype=dtype, weights='synthetic', seed=0)
+        call = (bench.make_inputs(args.batch, 512, torch.device("cuda")), "rgb")
     m(*call)
     torch.cuda.synchronize()
     ops.PROFILE = []
