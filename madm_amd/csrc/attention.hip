@@ -12,6 +12,7 @@
 // operand comes from ds_read_b64_tr_b16 (a 4-key x 16-d block transposed by the LDS), for f32
 // from four ds_read_b32.
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 #ifdef ATTN_STAMPS   // tools/exp/stamps_attn.py: shader-clock stamps per KV tile (block 0 / wave 0)
@@ -62,6 +63,9 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
     constexpr int ES = C::ES;
     constexpr int NT = C::NT;
     constexpr unsigned OOB = 0x80000000u;
+    // d = 40 in the 16-bit modes (the only head dim below its 16-column tiling: 48): column 40 of the V tile holds 1.0
+    constexpr bool ONES = (ND == 3) && (NKB == 2) && sizeof(T) == 2 && C::PIPE;
+    const uint4 vpad = ONES ? make_uint4(std::is_same<T, f16_t>::value ? 0x3C00u : 0x3F80u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* KV0 = smem + (C::Q_ALIAS ? 0 : C::BQ * C::QK_ROWB);
     char* Qs = C::Q_ALIAS ? KV0 + C::KV_TILE_B : smem;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
         }
         for (int idx = tid; idx < C::BKV * C::V_CH; idx += NT) {
             const int r = idx / C::V_CH, c = idx - r * C::V_CH;
-            if (c >= dch) *reinterpret_cast<uint4*>(Vb + r * C::V_ROWB + c * 16) = make_uint4(0, 0, 0, 0);
+            if (c >= dch) *reinterpret_cast<uint4*>(Vb + r * C::V_ROWB + c * 16) = (c == dch) ? vpad : make_uint4(0, 0, 0, 0);
         }
     }
     u32x4a kr[C::KI], vr[C::VI];
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
             }
             for (int idx = tid; idx < C::BKV * C::V_CH; idx += NT) {
                 const int r = idx / C::V_CH, c = idx - r * C::V_CH;
-                if (c >= dch) *reinterpret_cast<uint4*>(Vb + r * C::V_ROWB + c * 16) = make_uint4(0, 0, 0, 0);
+                if (c >= dch) *reinterpret_cast<uint4*>(Vb + r * C::V_ROWB + c * 16) = (c == dch) ? vpad : make_uint4(0, 0, 0, 0);
             }
         }
     }
@@ -240,6 +244,9 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
         }
         A_STAMP(t, 1);
         // ---- online softmax (base-2), one query per lane and query group ----
+        // [r4] three VALU operations per score instead of six: the running maximum is taken over the RAW scores (scale > 0)
+        // and the scale rides on the exponent's FMA, exp2(s * scale - m); with ONES the row sum comes out of the PV product
+        // (a ones column in the zero padding of the V tile: O[:, D] accumulates sum(P), rescaled with O) -- no per-score add
 #pragma unroll
         for (int g = 0; g < NQ; ++g) {
             float mx = -INFINITY;
@@ -247,19 +254,14 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
 #pragma unroll
                 for (int st = 0; st < NS; ++st)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = s[g][st][r] * p.scale_log2;
-                        s[g][st][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[g][st][r]);
             } else {
 #pragma unroll
                 for (int st = 0; st < NS; ++st)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = k0 + st * 16 + fg * 4 + r;
-                        float v = s[g][st][r] * p.scale_log2;
-                        v = (key < p.Lk) ? v : -INFINITY;
+                        const float v = (key < p.Lk) ? s[g][st][r] : -INFINITY;
                         s[g][st][r] = v;
                         mx = fmaxf(mx, v);
                     }
@@ -274,19 +276,20 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
                 const auto r32 = __builtin_amdgcn_permlane32_swap(yi, yi, false, false);
                 mx = fmaxf(__builtin_bit_cast(float, r32[0]), __builtin_bit_cast(float, r32[1]));
             }
-            const float m_new = fmaxf(m_run[g], mx);
+            const float m_new = fmaxf(m_run[g], mx * p.scale_log2);
             const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
             m_run[g] = m_new;
+            const float nm = -m_new;
             float psum = 0.f;
 #pragma unroll
             for (int st = 0; st < NS; ++st)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s[g][st][r] - m_new);
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[g][st][r], p.scale_log2, nm));
                     s[g][st][r] = e;
-                    psum += e;
+                    if constexpr (!ONES) psum += e;
                 }
-            l_run[g] = l_run[g] * alpha + psum;  // per lane-group partial; groups are summed at the end
+            if constexpr (!ONES) l_run[g] = l_run[g] * alpha + psum;  // per lane-group partial; groups are summed at the end
 #pragma unroll
             for (int d = 0; d < ND; ++d) o[g][d] *= alpha;
         }
@@ -364,9 +367,14 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
     // ---- finish: total row sum over the 4 lane groups, normalise, store 4 consecutive d ----
 #pragma unroll
     for (int g = 0; g < NQ; ++g) {
-        float l = l_run[g];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if constexpr (ONES) {   // column 40 of O: tile d = 2, lane group fg = 2, element 0 -> every lane group of the query
+            l = __shfl(o[g][2][0], 32 + fi);
+        } else {
+            l = l_run[g];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         const float inv = 1.0f / l;
         const int qi = q0 + (wave * NQ + g) * 16 + fi;
         if (qi < p.Lq) {

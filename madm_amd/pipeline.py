@@ -35,6 +35,26 @@ class StagedExtractor:
         if streams is not None:       # reuse another (idle) pipeline's streams: they already sit on pipes of their own
             assert len(streams) == self.k + 1
             self.s_enc, self.s_unet = streams[0], list(streams[1:])
+        elif os.environ.get("MADM_EXP_CUMASK"):
+            # experiment: "<enc_lo>-<enc_hi>,<unet_lo>-<unet_hi>" = CU ranges (of 256) the encoder stream / the UNet streams may
+            # use (hipExtStreamCreateWithCUMask): does keeping the chip-filling encoder kernels off some CUs shorten the wait
+            # of the UNet's small grids for slots?  
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+
+            def masked(lo, hi):
+                words = (ctypes.c_uint32 * 8)()
+                for b_ in range(lo, hi):
+                    words[b_ // 32] |= 1 << (b_ % 32)
+                st = ctypes.c_void_p()
+                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+                assert rc == 0, f"hipExtStreamCreateWithCUMask failed: {rc}"
+                return torch.cuda.ExternalStream(st.value, device=dev)
+            enc, un = os.environ["MADM_EXP_CUMASK"].split(",")
+            e0, e1 = (int(v) for v in enc.split("-"))
+            u0, u1 = (int(v) for v in un.split("-"))
+            self.s_enc = masked(e0, e1)
+            self.s_unet = [masked(u0, u1) for _ in range(self.k)]
         else:
             # experiment switch MADM_EXP_PRIO: "u" = UNet streams high priority, "e" = encoder stream high priority
             prio = os.environ.get("MADM_EXP_PRIO", "")

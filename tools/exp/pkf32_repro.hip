@@ -131,8 +131,9 @@ __global__ __launch_bounds__(256, 2) void repro(int iters, int partner, int part
                             : [x] "v"(x), [mm] "v"(mm), [x0] "v"(x[0]), [x1] "v"(x[1]), [mean] "v"(mean), [rr] "v"(rr), [rstd] "v"(rstd),
                               [lim] "v"(lim), [l16] "v"(l16)
                             : "vcc");
-                    if ((unsigned)l16 < lim && (__builtin_bit_cast(unsigned, d[0]) != __builtin_bit_cast(unsigned, g0) ||
-                                                __builtin_bit_cast(unsigned, d[1]) != __builtin_bit_cast(unsigned, g1))) {
+                    // only the LOW result is compared: it is the half that failed in the kernel (the high half of this
+                    // stand-alone pair differs from its scalar twin for a reason of the harness, not of the hardware)
+                    if ((unsigned)l16 < lim && __builtin_bit_cast(unsigned, d[0]) != __builtin_bit_cast(unsigned, g0)) {
                         // counted in registers (one atomic per thread at the end: a storm of same-address atomics would
                         // look like a hang); only a thread's FIRST mismatch is recorded
                         if (__builtin_bit_cast(unsigned, d[0]) != __builtin_bit_cast(unsigned, g0)) ++n_lo; else ++n_hi;

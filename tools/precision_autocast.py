@@ -17,7 +17,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(case_name, unet_weights="f16", threads=None, f32_schedule=False):
+def run_all(case_name, unet_weights="f16", threads=None, variants=(False, True)):
+    """-> {f32_schedule: (rows, seconds)} and the fp32 oracle's seconds; ONE model build and ONE fp32 reference run."""
     from golden_util import CASES, make_inputs
     from madm_amd import weights
     from oracle import sd_modules, ldm_path
@@ -36,26 +37,33 @@ def run(case_name, unet_weights="f16", threads=None, f32_schedule=False):
     half_parameters_(vae)                       # torch_dtype=torch.float16 (ldm_diffusers.py:248)
     if unet_weights == "f16":
         half_parameters_(unet)                  # frozen UNet: torch.float16 (:253); 'f32' = the fine-tuned UNet under autocast
-    if f32_schedule:
+
+    class _F32Schedule:
         # diffusers' add_noise casts alphas_cumprod to the latents' dtype (oracle/sd_modules.py DDPMScheduler.add_noise, the
         # restated diffusers 0.25 code): with fp16 latents sqrt(1 - fp16(0.99915)) = 0.03125 instead of 0.02915 at t = 0.
-        # This switch keeps the latents fp32 through add_noise to show the rest of the arithmetic on its own.
-        class _S:
-            def add_noise(self, x, n, t):
-                return sched.add_noise(x.float(), n, t)
-        sched_emu = _S()
-    else:
-        sched_emu = sched
-    t0 = time.time()
-    with torch.no_grad(), CudaAutocastF16():
-        emu = ldm_path.ldm_forward(vae, unet, sched_emu, noise, images, cond, cond_emb, timesteps=timesteps)
-    t_emu = time.time() - t0
-    rows = []
-    pairs = [("latents", emu["latents"], ref["latents"]), ("sample", emu["sample"], ref["sample"])]
-    pairs += [(f"tap{i}", a, b) for i, (a, b) in enumerate(zip(emu["unet_features"], ref["unet_features"]))]
-    for name, a, b in pairs:
-        a, b = a.float(), b.float()
-        rows.append((name, tuple(b.shape), float((a - b).norm() / b.norm()), float((a - b).abs().max() / b.abs().max())))
+        # This variant keeps the latents fp32 through add_noise to show the rest of the arithmetic on its own.
+        def add_noise(self, x, n, t):
+            return sched.add_noise(x.float(), n, t)
+
+    out = {}
+    for f32_schedule in variants:
+        t0 = time.time()
+        with torch.no_grad(), CudaAutocastF16():
+            emu = ldm_path.ldm_forward(vae, unet, _F32Schedule() if f32_schedule else sched, noise, images, cond, cond_emb,
+                                       timesteps=timesteps)
+        rows = []
+        pairs = [("latents", emu["latents"], ref["latents"]), ("sample", emu["sample"], ref["sample"])]
+        pairs += [(f"tap{i}", a, b) for i, (a, b) in enumerate(zip(emu["unet_features"], ref["unet_features"]))]
+        for name, a, b in pairs:
+            a, b = a.float(), b.float()
+            rows.append((name, tuple(b.shape), float((a - b).norm() / b.norm()), float((a - b).abs().max() / b.abs().max())))
+        out[f32_schedule] = (rows, time.time() - t0)
+    return out, t_ref
+
+
+def run(case_name, unet_weights="f16", threads=None, f32_schedule=False):
+    out, t_ref = run_all(case_name, unet_weights, threads, variants=(f32_schedule,))
+    rows, t_emu = out[f32_schedule]
     return rows, t_ref, t_emu
 
 
@@ -64,8 +72,9 @@ def main():
     ap.add_argument("--case", default="full_t0")
     ap.add_argument("--unet-weights", default="f16", choices=["f16", "f32"])
     args = ap.parse_args()
+    out, t_ref = run_all(args.case, args.unet_weights)
     for f32_schedule in (False, True):
-        rows, t_ref, t_emu = run(args.case, args.unet_weights, f32_schedule=f32_schedule)
+        rows, t_emu = out[f32_schedule]
         print(f"case {args.case}: fp32 oracle {t_ref:.1f} s, fp16-autocast emulation {t_emu:.1f} s on {torch.get_num_threads()} threads; "
               f"VAE weights f16, UNet weights {args.unet_weights}; add_noise coefficients "
               + ("in fp32 (NOT what the reference does: isolates the rest)" if f32_schedule else
