@@ -849,7 +849,19 @@ int pick_tile(const madm_conv2d_args* a) {
                 if (t->tile == 13) return 13;
         }
     }
-    if (h16_upsample_eligible(a) && (g_tile_override == 12 || (g_tile_override == 0 && h16_pays(a)))) return 12;
+    if (h16_upsample_eligible(a)) {
+        if (g_tile_override == 12) return 12;
+        if (g_tile_override == 0) {
+            // a table row decides (variant 2; the side-by-side tuner put the UNet's upsample convs here although their grids
+            // are far below a round of workgroups), h16_pays() where there is none
+            const int M = a->B * a->OH * a->OW, K = a->KH * a->KW * (a->C1 + a->C2);
+            if (const Tuned* t = find_tuned(a->dtype, M, a->N, K, a->KH, 2)) {
+                if (t->tile == 12) return 12;
+            } else if (h16_pays(a)) {
+                return 12;
+            }
+        }
+    }
     const int t = pick_tile_raw(a);
     if (t == 12 && (a->OH < 16 || a->OW < 16)) return 9;   // the 16 x 16-patch kernel needs a map of at least one patch
     if ((t == 4 || t == 9) && g_tile_override == 0 && h16_pays(a)) return 12;

@@ -235,12 +235,17 @@ def test_train_step_matches_fixture(cuda, variant, dtype):
             p.grad.div_(gscale)
     f32 = dtype == torch.float32
     ltol = 1e-4 if f32 else (1e-2 if dtype == torch.float16 else 5e-2)
+    # Discontinuities of the step: the teacher's argmax (two classes tying to ~1e-7) and its confidence threshold (a
+    # probability within ~1e-7 of pseudo_threshold: pseudo_weight = share of the pixels above it moves by 1 / pixels).  The
+    # device and the CPU oracle sum in different orders, so such a pixel may fall the other way; everything computed from the
+    # mask / the weight then legitimately differs by that pixel's share.  At most 2 pixels, and the loss gate widens to 2e-3.
     flips = int((model.last_step["pseudo_label"].cpu().to(torch.uint8) != gold["pseudo_label"]).sum())
-    if f32 and flips:
-        # a near-tie of the teacher's two best classes (|dp| ~ 1e-7) resolved the other way than in the CPU oracle: the
-        # ClassMix mask, hence the mixed target image and everything computed from it, legitimately differ by that pixel
-        print(f"pseudo-label near-tie flips: {flips} of {gold['pseudo_label'].numel()} pixels")
-        assert flips <= 2
+    npix = gold["pseudo_label"][0].numel()
+    quanta = abs(model.last_step["pseudo_weight"].flatten()[0].item() - gold["pseudo_weight0"].item()) * npix
+    near_tie = f32 and (flips > 0 or quanta > 0.5)
+    if near_tie:
+        print(f"near-tie pixels: {flips} label flips, {quanta:.3f} threshold crossings (of {npix} pixels per image)")
+        assert flips <= 2 and quanta < 2.01 and abs(quanta - round(quanta)) < 0.02
         ltol = 2e-3
     rep = []
     for k, v in losses.items():
@@ -255,8 +260,11 @@ def test_train_step_matches_fixture(cuda, variant, dtype):
         for key in ("pseudo_label", "mixed_lbl"):
             flips = int((ls[key].cpu().to(torch.uint8) != gold[key]).sum())
             assert flips <= 2, (key, flips)
-        assert abs(ls["pseudo_weight"].flatten()[0].item() - gold["pseudo_weight0"].item()) < 1e-6
-        assert rel_err(ls["mixed_seg_weight"].cpu(), gold["mixed_seg_weight"])[0] < 1e-6
+        if not near_tie:
+            assert abs(ls["pseudo_weight"].flatten()[0].item() - gold["pseudo_weight0"].item()) < 1e-6
+            assert rel_err(ls["mixed_seg_weight"].cpu(), gold["mixed_seg_weight"])[0] < 1e-6
+        else:
+            assert rel_err(ls["mixed_seg_weight"].cpu(), gold["mixed_seg_weight"])[0] < 2e-3
     else:
         assert (ls["pseudo_label"].cpu().to(torch.uint8) == gold["pseudo_label"]).float().mean() > 0.9
     K = 11
