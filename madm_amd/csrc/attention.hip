@@ -56,6 +56,18 @@ struct AttnCfg {
 };
 
 typedef unsigned int u32x4a __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2a __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int N> __device__ __forceinline__ void attn_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// waits until at most ``young`` LDS reads issued after the awaited one are outstanding (young is a constant after unrolling)
+__device__ __forceinline__ void attn_wait_young(int young) {
+    if (young >= 4) attn_wait_lgkm<4>();
+    else if (young == 3) attn_wait_lgkm<3>();
+    else if (young == 2) attn_wait_lgkm<2>();
+    else if (young == 1) attn_wait_lgkm<1>();
+    else attn_wait_lgkm<0>();
+}
+#endif
 
 template <typename T, int NKB, int ND, int NW, int NS, int NQ = 1>
 __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const AttnP p) {
@@ -65,6 +77,11 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
     constexpr unsigned OOB = 0x80000000u;
     // d = 40 in the 16-bit modes (the only head dim below its 16-column tiling: 48): column 40 of the V tile holds 1.0
     constexpr bool ONES = (ND == 3) && (NKB == 2) && sizeof(T) == 2 && C::PIPE;
+    // [r4] 16-bit pipelined configurations: the K fragment reads of S = K Q^T are software-pipelined by hand (inline-asm
+    // ds_read_b128, four reads ahead of the MFMAs that consume them, counted lgkmcnt) -- hipcc's schedule waited a full LDS
+    // round trip in front of every pair of MFMAs in the first half of the product (in-kernel stamps, d = 40, 128-key tile:
+    // 1 490 -> 1 220 clocks for the next tile's global loads + 32 MFMAs)
+    constexpr bool MANUAL = C::PIPE && sizeof(T) == 2 && NS % 2 == 0;
     const uint4 vpad = ONES ? make_uint4(std::is_same<T, f16_t>::value ? 0x3C00u : 0x3F80u, 0, 0, 0) : make_uint4(0, 0, 0, 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* KV0 = smem + (C::Q_ALIAS ? 0 : C::BQ * C::QK_ROWB);
@@ -227,6 +244,31 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
         for (int g = 0; g < NQ; ++g)
 #pragma unroll
             for (int st = 0; st < NS; ++st) s[g][st] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MANUAL) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            constexpr int NIT = NKB * NS, KD = 4;
+            const unsigned kbase = (unsigned)(size_t)Ks + (unsigned)(fi * C::QK_ROWB + fg * 16);
+            u32x4a kf[KD + 1];
+            attn_wait_lgkm<0>();          // nothing of the compiler's is left on the counter the waits below count on
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < KD && i < NIT; ++i)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[i]) : "v"(kbase),
+                             "n"(((i % NS) * 16) * C::QK_ROWB + (i / NS) * 64));
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                if (i + KD < NIT)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[(i + KD) % (KD + 1)]) : "v"(kbase),
+                                 "n"((((i + KD) % NS) * 16) * C::QK_ROWB + ((i + KD) / NS) * 64));
+                attn_wait_young((NIT - 1 - i < KD) ? NIT - 1 - i : KD);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < NQ; ++g)
+                    mma16<T>(__builtin_bit_cast(uint4, kf[i % (KD + 1)]), qreg[g][i / NS], s[g][i % NS]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        } else {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             uint4 qf[NQ];
@@ -241,6 +283,7 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
 #pragma unroll
                 for (int g = 0; g < NQ; ++g) mma16<T>(kf, qf[g], s[g][st]);
             }
+        }
         }
         A_STAMP(t, 1);
         // ---- online softmax (base-2), one query per lane and query group ----
@@ -299,6 +342,9 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
         if constexpr (sizeof(T) == 2) {
             static_assert(sizeof(T) != 2 || NS % 2 == 0, "bf16 path pairs key sub-tiles");
             const int tq = fi >> 2, tp = fi & 3;
+            // (the same hand-pipelining of the V fragment reads was built and measured: 1 720 vs 1 610 clocks for this phase --
+            //  it takes the P conversion and the exponentials of the second query group out of the MFMA stream, which hipcc
+            //  interleaves; the SIMD is issue-bound here, not latency-bound)
 #pragma unroll
             for (int u = 0; u < NS / 2; ++u) {
                 uint4 pfu[NQ];
