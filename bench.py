@@ -241,8 +241,8 @@ def kernel_profile(model, inputs):
     return agg
 
 
-CALIB_REF = {"mfma_loop_tflops": 2283.0, "h16_128x128_512sq_us": 166.0}   # DESIGN.md section 8 (round 2 box): the loop's
-# rate and the unfused 128 -> 128 3x3 layer at 2 x 512^2 of the 16 x 16 halo kernel -- what value_normalised refers to
+CALIB_REF = {"mfma_loop_tflops": 2000.0, "h16_128x128_512sq_us": 141.0}   # the middle of the boxes seen in round 4 with
+# exactly these two measurements (loop 1 835 .. 2 022 TFLOP/s, layer 139.5 .. 145.8 us): what value_normalised refers to
 
 
 def calibrate(device, dtype):

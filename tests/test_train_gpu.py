@@ -247,6 +247,8 @@ def test_train_step_matches_fixture(cuda, variant, dtype):
     npix = gold["pseudo_label"][0].numel()
     # (the fixture keeps image 0's pseudo_weight only; every image's weight shows in mixed_seg_weight)
     quanta = float((model.last_step["mixed_seg_weight"].cpu() - gold["mixed_seg_weight"]).abs().max()) * npix
+    # (... where the mix mask takes the target image; image 0's weight itself is compared as well)
+    quanta = max(quanta, abs(model.last_step["pseudo_weight"].flatten()[0].item() - gold["pseudo_weight0"].item()) * npix)
     near_tie = f32 and (flips > 0 or quanta > 0.5)
     if near_tie:
         print(f"near-tie pixels: {flips} label flips, {quanta:.3f} threshold crossings (of {npix} pixels per image)")
