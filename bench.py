@@ -209,10 +209,12 @@ def kernel_profile(model, inputs):
     """Two eager passes with HIP events around every MFMA-kernel launch (events recorded on the launch stream).
 
     * raw: one event pair per launch -- the bracket holds the kernel plus the marker / dispatch cost of the pair;
-    * differenced (conv / GEMM launches): the launch is issued three times as [K] [K K] between three events
+    * differenced (conv / GEMM / attention launches): the launch is issued three times as [K] [K K] between three events
       (ops.PROFILE_DIFF); bracket 2 - bracket 1 = one launch with the pair's constant cost cancelled.  This replaces
       round 2's "empty bracket" overhead estimate, which over-corrected (8.6 us subtracted per launch where
-      rocprofv3's timestamps implied ~4.6).  Launches without a differenced figure (attention) keep the raw one.
+      rocprofv3's timestamps implied ~4.6).  Launches without a differenced figure (the stem) keep the raw one.
+      (Round 4: attention too -- its 22 short launches at L <= 1024 read 18 .. 21 us each by single pairs against 8 .. 22 us by
+      rocprofv3's timestamps of the same kernels, profiles/round4_final_last_replay.txt.)
 
     Returns {kernel: (launches, raw_ms, algorithmic_flops, algorithmic_bytes, differenced_ms)}."""
     from madm_amd import ops

@@ -720,7 +720,7 @@ __global__ __launch_bounds__(PGN_THREADS) void splitk_groupnorm_kernel(const Ige
 inline size_t post_gn_lds(int HW, int N, int G) { return (size_t)HW * (size_t)(N / G) * sizeof(float); }
 
 int g_tile_override = 0;  // 0 = tuned table then heuristic; -1 = heuristic only; 1..6 = forced tile code
-inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8) || t == 11 || t == 14 || t == 15; }
+inline bool is_igemm_tile(int t) { return t <= 3 || (t >= 6 && t <= 8) || t == 11 || (t >= 14 && t <= 17); }
 // tile 13 (igemm_apanel.hip): plain linear layer, one source, whole rows resident: no split-K, no residual / time row /
 // fused output statistics (its epilogue touches no global memory but the stores)
 inline bool apanel_eligible(const madm_conv2d_args* a) {
@@ -871,7 +871,7 @@ int pick_tile(const madm_conv2d_args* a) {
 void tile_dims(int t, int& bm, int& bn) {
     if (t == 12) { bm = 256; bn = 128; }
     else if (t == 1 || t == 4 || t == 9 || t == 14 || t == 15) { bm = 128; bn = 128; }
-    else if (t == 2 || t == 5 || t == 8 || t == 10) { bm = 128; bn = 64; }
+    else if (t == 2 || t == 5 || t == 8 || t == 10 || t == 17) { bm = 128; bn = 64; }
     else { bm = 64; bn = 64; }
 }
 
@@ -980,6 +980,10 @@ int launch(const IgemmP& p0, int t, hipStream_t s, const PostGn& pn) {
         else if (t == 11) { if (int e = launch_glds<T, 64, 64, 3>(p, grid, s)) return e; }
         else if (t == 14) { if (int e = launch_glds<T, 128, 128, 3>(p, grid, s)) return e; }
         else if (t == 15) { if (int e = launch_glds<T, 128, 128, 2>(p, grid, s)) return e; }
+        // two-slot rings of the small tiles: 32 / 48 KB of LDS = five / three blocks per CU (short-K layers: the blocks'
+        // prologues and epilogues cover each other instead of a deep ring covering the K loop)
+        else if (t == 16) { if (int e = launch_glds<T, 64, 64, 2>(p, grid, s)) return e; }
+        else if (t == 17) { if (int e = launch_glds<T, 128, 64, 2>(p, grid, s)) return e; }
         else if (lin) igemm_kernel<T, 64, 64, 4, true><<<grid, 256, 0, s>>>(p);
         else igemm_kernel<T, 64, 64, 4, false><<<grid, 256, 0, s>>>(p);
         rc = madm_check_launch("igemm_kernel");

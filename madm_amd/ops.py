@@ -56,7 +56,8 @@ PROFILE_DIFF = False
 _TILE_NAMES = {1: "igemm_128x128", 2: "igemm_128x64", 3: "igemm_64x64", 4: "conv3x3_halo_x128", 5: "conv3x3_halo_x64",
                6: "igemm_64x64d", 7: "igemm_glds_64x64", 8: "igemm_glds_128x64", 9: "conv3x3_halo_dma_x128",
                10: "conv3x3_halo_dma_x64", 11: "igemm_glds_64x64s", 12: "conv3x3_h16_x128", 13: "igemm_apanel",
-               14: "igemm_glds_128x128", 15: "igemm_glds_128x128d"}
+               14: "igemm_glds_128x128", 15: "igemm_glds_128x128d",
+               16: "igemm_glds_64x64d", 17: "igemm_glds_128x64d"}
 EXP_NO_STATS = bool(int(__import__('os').environ.get('MADM_EXP_NO_STATS', '0')))   # timing experiment only
 FORCE_SPLITK = None   # tools/tune_insitu.py: split-K factor forced on every small-M launch
 if os.environ.get("MADM_EXP_SPLITK"):   # experiment: e.g. 1 = no split-K anywhere (does the staged pipeline still want it?)
@@ -240,7 +241,9 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         an, ak = alg_nk if alg_nk is not None else (N, KH * KW * (C1 + C2))
         name = _TILE_NAMES[lib.madm_conv2d_pick_tile(ctypes.byref(a))] + _SUFFIX[x1.dtype]
         desc = (f"M{M} N{N} K{KH * KW * (C1 + C2)} k{KH} s{stride}{' up' if upsample else ''}"
-                f"{' gn' if gn is not None else ''} sk{a.splitk}{' +gn' if applied else ''}")
+                f"{' gn' if gn is not None else ''}{' ln' if ln is not None else ''}"
+                f"{' geglu' if epilogue == EPI_GEGLU else ''}{' res' if residual is not None else ''}"
+                f" sk{a.splitk}{' +gn' if applied else ''}")
         es = x1.element_size()
         # algorithmic HBM bytes: every input element, weight and output element once
         nbytes = (B * IH * IW * (C1 + C2) * es + w.numel() * es
@@ -640,8 +643,13 @@ def attention(q, k, v, B, H, Lq, Lk, D, scale, out=None):
     if "attention" in EXP_SKIP or (EXP_SKIP and _skip_match(f"attn d{D} Lq{Lq} Lk{Lk}")):
         return out
     with _Prof(f"attn_d{D}" + _SUFFIX[q.dtype], 4.0 * B * H * Lq * Lk * D,
-               f"B{B} H{H} Lq{Lq} Lk{Lk}"):
+               f"B{B} H{H} Lq{Lq} Lk{Lk}") as pr:
         check(lib.madm_attention_fwd(ctypes.byref(a), _stream()), "madm_attention_fwd")
+    if PROFILE is not None and PROFILE_DIFF:   # [K] [K K] like the conv / GEMM launches (the launch is idempotent)
+        check(lib.madm_attention_fwd(ctypes.byref(a), _stream()), "madm_attention_fwd")
+        check(lib.madm_attention_fwd(ctypes.byref(a), _stream()), "madm_attention_fwd")
+        pr.e2 = torch.cuda.Event(enable_timing=True)
+        pr.e2.record()
     return out
 
 

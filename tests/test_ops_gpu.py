@@ -72,6 +72,12 @@ CONV_CASES = [
     ("glds128sq2_3x3_ragged", 1, [64], 13, 21, 192, 3, 1, "same", False, 15, 1),
     ("glds128sq2_upsample_splitk", 2, [128], 6, 6, 64, 3, 1, "same", True, 15, 3),
     ("glds128sq2_onetile", 2, [64], 8, 8, 64, 1, 1, "none", False, 15, 1),
+    ("glds64d_1x1_longk", 2, [1280], 8, 16, 320, 1, 1, "none", False, 16, 1),
+    ("glds64d_3x3_ragged", 1, [64], 13, 21, 192, 3, 1, "same", False, 16, 1),
+    ("glds64d_concat_s2_splitk", 2, [128, 64], 16, 16, 192, 3, 2, "same", False, 16, 2),
+    ("glds128x64d_1x1_longk", 2, [1280], 8, 16, 320, 1, 1, "none", False, 17, 1),
+    ("glds128x64d_3x3_ragged", 1, [64], 13, 21, 192, 3, 1, "same", False, 17, 1),
+    ("glds128x64d_upsample_splitk", 2, [128], 6, 6, 64, 3, 1, "same", True, 17, 3),
     ("glds64s_1x1", 2, [320], 8, 8, 320, 1, 1, "none", False, 11, 1),
     ("glds64s_ragged_3x3_splitk", 2, [128], 5, 7, 192, 3, 1, "same", False, 11, 2),
     # 9 / 10 = halo conv with LDS-DMA weights (three-slot ring, single halo buffer)
@@ -254,6 +260,10 @@ LN_FOLD_CASES = [
     ("glds128sq_geglu", 256, 640, 1024, 14, True, False),
     ("glds128sq2_q_res", 200, 1280, 640, 15, False, True),
     ("glds128sq2_fullchip_geglu", 8192, 320, 2560, 15, True, False),
+    ("glds64d_qkv", 300, 320, 960, 16, False, False),
+    ("glds64d_geglu", 256, 640, 1024, 16, True, False),
+    ("glds128x64d_q_res", 200, 1280, 640, 17, False, True),
+    ("glds128x64d_geglu", 1024, 320, 2560, 17, True, False),
     ("reg64x64", 96, 64, 128, 3, False, True),
     ("reg64x64d", 70, 128, 64, 6, False, False),
     # tile 13 = A-stationary kernel (igemm_apanel.hip): resident row panel (BM = 128 / 64 / 32 by K), LayerNorm in place

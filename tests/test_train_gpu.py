@@ -244,14 +244,13 @@ def test_train_step_matches_fixture(cuda, variant, dtype):
     # flip against the stored array, 0.194572 with none -- the fixture's loss and its stored label array sit on different
     # sides).  So: at most 2 flipped pixels / threshold crossings, and the TARGET-side losses are gated at 1e-3 in f32.
     flips = int((model.last_step["pseudo_label"].cpu().to(torch.uint8) != gold["pseudo_label"]).sum())
-    npix = gold["pseudo_label"][0].numel()
-    # (the fixture keeps image 0's pseudo_weight only; every image's weight shows in mixed_seg_weight)
+    npix = gold["pseudo_label"].numel()          # the weight is ONE share over the whole batch (dacs_transforms / labels.py:38)
     quanta = float((model.last_step["mixed_seg_weight"].cpu() - gold["mixed_seg_weight"]).abs().max()) * npix
-    # (... where the mix mask takes the target image; image 0's weight itself is compared as well)
+    # (... seen where the mix mask takes the target image; the weight itself is compared as well)
     quanta = max(quanta, abs(model.last_step["pseudo_weight"].flatten()[0].item() - gold["pseudo_weight0"].item()) * npix)
     near_tie = f32 and (flips > 0 or quanta > 0.5)
     if near_tie:
-        print(f"near-tie pixels: {flips} label flips, {quanta:.3f} threshold crossings (of {npix} pixels per image)")
+        print(f"near-tie pixels: {flips} label flips, {quanta:.3f} threshold crossings (of {npix} pixels)")
         assert flips <= 2 and quanta < 2.01 and abs(quanta - round(quanta)) < 0.02
     rep = []
     for k, v in losses.items():

@@ -19,15 +19,16 @@ import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-LIN_TILES = [1, 2, 3, 7, 8, 11, 14, 15]
-CONV_TILES = [2, 7, 8, 9, 10, 11, 12, 14, 15]
+LIN_TILES = [1, 2, 3, 7, 8, 11, 14, 15, 16, 17]
+CONV_TILES = [2, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17]
 SPLITS = [1, 2, 3, 4, 6, 8, 12, 24]
 
 
 def parse_desc(desc):
-    m = re.match(r"M(\d+) N(\d+) K(\d+) k(\d+) s(\d+)( up)?( gn)? sk(\d+)", desc)
-    M, N, K, k, s, up, gn, sk = m.groups()
-    return dict(M=int(M), N=int(N), K=int(K), k=int(k), s=int(s), up=bool(up), gn=bool(gn), sk=int(sk))
+    m = re.match(r"M(\d+) N(\d+) K(\d+) k(\d+) s(\d+)( up)?( gn)?( ln)?( geglu)?( res)? sk(\d+)", desc)
+    M, N, K, k, s, up, gn, ln, geglu, res, sk = m.groups()
+    return dict(M=int(M), N=int(N), K=int(K), k=int(k), s=int(s), up=bool(up), gn=bool(gn), ln=bool(ln), geglu=bool(geglu),
+                res=bool(res), sk=int(sk))
 
 
 class Layer:
@@ -55,6 +56,12 @@ class Layer:
             ops.groupnorm_stats(self.xs[0], B, self.IH * self.IH, sums)
             self.gn = ([sums], torch.rand(self.Cin, device="cuda") + 0.5, torch.randn(self.Cin, device="cuda") * 0.1, 32, 1e-5, True)
         self.st = torch.zeros((B, N, 2), dtype=torch.float64, device="cuda") if k == 3 else None
+        # the layer's own epilogue: folded LayerNorm (row sums from the A fragments), GEGLU (half the columns stored, one erf
+        # per pair), residual -- the tile that wins a plain GEMM of the shape need not win these
+        self.ln = (torch.randn(N, device="cuda"), 1e-5) if d["ln"] else None
+        self.epi = ops.EPI_GEGLU if d["geglu"] else ops.EPI_NONE
+        ocols = N // 2 if d["geglu"] else N
+        self.res = [torch.randn((M, ocols), device="cuda").to(dtype) for _ in range(Rx)] if d["res"] else None
         self.it = 0
 
     def run(self, sk):
@@ -64,7 +71,9 @@ class Layer:
         k = d["k"]
         pad = k // 2
         return self.ops.conv2d(x, w, self.B, self.IH, self.IH, N=d["N"], KH=k, KW=k, stride=d["s"], pad_t=pad, pad_l=pad,
-                               OH=self.OH, OW=self.OH, upsample=d["up"], bias=self.bias, stats=self.st, gn=self.gn, splitk=sk)
+                               OH=self.OH, OW=self.OH, upsample=d["up"], bias=self.bias, stats=self.st, gn=self.gn, splitk=sk,
+                               ln=self.ln, epilogue=self.epi,
+                               residual=None if self.res is None else self.res[self.it % len(self.res)])
 
 
 def time_candidate(layers, sk, reps, streams):
@@ -179,7 +188,7 @@ def main():
             if t in (9, 10) and (d["k"] != 3 or d["s"] != 1 or d["up"]):
                 continue
             for sk in SPLITS:
-                if sk > max(1, nk // 2) or (t == 13 and sk > 1):
+                if sk > max(1, nk // 2) or (t == 13 and sk > 1) or (d["ln"] and sk > 1):
                     continue
                 if t in (9, 10, 12) and sk > max(1, layers[0].Cin // 64):
                     continue
