@@ -184,6 +184,43 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
 }
 
+// All kernel-argument cache lines requested at once, first thing in a kernel.  The compiler fetches a by-value parameter
+// struct piecemeal, where each field is first used: three or four DEPENDENT scalar-cache misses (~0.3 us each on a cold
+// scalar cache -- every block of a one-round launch is the first on its CU) in front of the first operand load of the
+// igemm kernels (in-kernel stamps, tools/exp/stamps_reg.py: 1 400 clocks from entry to the first load).  One blocking touch
+// of every 64-byte line makes the later loads hit.  LINES x 64 B must cover the explicit arguments and the hidden ones
+// behind them (grid size ...).
+template <int LINES>
+__device__ __forceinline__ void kernarg_touch() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(LINES >= 1 && LINES <= 6, "kernarg_touch: 1 .. 6 lines");
+    const auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    unsigned t0, t1, t2, t3, t4, t5;
+    if constexpr (LINES == 6)
+        asm volatile("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\t"
+                     "s_load_dword %3, %6, 0xc0\n\ts_load_dword %4, %6, 0x100\n\ts_load_dword %5, %6, 0x140\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5) : "s"(ka) : "memory");
+    else if constexpr (LINES == 5)
+        asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x40\n\ts_load_dword %2, %5, 0x80\n\t"
+                     "s_load_dword %3, %5, 0xc0\n\ts_load_dword %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4) : "s"(ka) : "memory");
+    else if constexpr (LINES == 4)
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\t"
+                     "s_load_dword %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(ka) : "memory");
+    else if constexpr (LINES == 3)
+        asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %3, 0x40\n\ts_load_dword %2, %3, 0x80\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2) : "s"(ka) : "memory");
+    else if constexpr (LINES == 2)
+        asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1) : "s"(ka) : "memory");
+    else
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t0) : "s"(ka) : "memory");
+#endif
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per device (bit per
 // device id in ``done``, atomic: host threads may launch concurrently).  ``done`` is a function-local static of the caller,
 // i.e. one per kernel instantiation.

@@ -17,6 +17,7 @@ namespace {
 
 template <typename T, int BN, bool FUSE, int NWS>
 __global__ __launch_bounds__(256, (NWS == 2 || BN == 64) ? 2 : 1) void conv3x3_halo_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
+    kernarg_touch<5>();
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;
     constexpr int MI = 4, NI = BN / 32;     // wave tile: 4 patch rows (64 px) x BN/2 channels

@@ -35,22 +35,30 @@ __device__ __forceinline__ void halo_tile_epilogue(const IgemmP& p, f32x4 (&acc)
 #pragma unroll
     for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     if (p.splitk == 1) epilogue_consts<NI>(p, nb, b, add);   // a patch lies in one image
+    int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int oy = py0 + wm * 4 + i, ox = px0 + frow;
-        if (oy >= p.OH || ox >= p.OW) continue;
-        const int m = (b * p.OH + oy) * p.OW + ox;
-        if (p.splitk > 1) {
+        mrow[i] = (oy < p.OH && ox < p.OW) ? (b * p.OH + oy) * p.OW + ox : -1;
+    }
+    if (p.splitk > 1) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (mrow[i] < 0) continue;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const f32x4 v = acc[i][j];
                 if (nb + 16 * j < p.N)
-                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + nb + 16 * j) =
+                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + mrow[i]) * p.N + nb + 16 * j) =
                         make_float4(v[0], v[1], v[2], v[3]);
             }
-        } else {
-            epilogue_row<T, NI>(p, m, nb, add, false, acc[i]);
-            if (want_stats) {
+        }
+    } else {
+        epilogue_tile<T, MI, NI>(p, mrow, nb, add, false, acc);
+        if (want_stats) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (mrow[i] < 0) continue;
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     if (nb + 16 * j < p.N) { cs[j] += acc[i][j]; cq[j] += acc[i][j] * acc[i][j]; }

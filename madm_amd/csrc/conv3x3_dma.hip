@@ -19,6 +19,7 @@ template <int N> __device__ __forceinline__ void c3_wait_lgkmcnt() { asm volatil
 
 template <typename T, int BN, bool FUSE>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
+    kernarg_touch<5>();
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS address-space casts and gfx asm: device pass only (the host needs the stub)
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;

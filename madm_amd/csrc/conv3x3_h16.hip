@@ -82,21 +82,29 @@ __device__ __forceinline__ void h16_epilogue(const IgemmP& p, f32x4 (&acc)[MI][B
 #pragma unroll
     for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     if (p.splitk == 1) epilogue_consts<NI>(p, nb, b, add);
+    int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int oy = py0 + wm * MI + i, ox = px0 + frow;
-        if (oy >= p.OH || ox >= p.OW) continue;
-        const int m = (b * p.OH + oy) * p.OW + ox;
-        if (p.splitk > 1) {
+        mrow[i] = (oy < p.OH && ox < p.OW) ? (b * p.OH + oy) * p.OW + ox : -1;
+    }
+    if (p.splitk > 1) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (mrow[i] < 0) continue;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const f32x4 v = acc[i][j];
                 if (nb + 16 * j < p.N)
-                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + nb + 16 * j) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + mrow[i]) * p.N + nb + 16 * j) = make_float4(v[0], v[1], v[2], v[3]);
             }
-        } else {
-            epilogue_row<T, NI>(p, m, nb, add, false, acc[i]);
-            if (want_stats) {
+        }
+    } else {
+        epilogue_tile<T, MI, NI>(p, mrow, nb, add, false, acc);
+        if (want_stats) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (mrow[i] < 0) continue;
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     if (nb + 16 * j < p.N) { cs[j] += acc[i][j]; cq[j] += acc[i][j] * acc[i][j]; }
@@ -265,6 +273,7 @@ __device__ __forceinline__ void h16_epilogue_lds(const IgemmP& p, f32x4 (&acc)[M
 
 template <typename T, int BN, bool FUSE, bool WIDE>
 __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
+    kernarg_touch<5>();
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;

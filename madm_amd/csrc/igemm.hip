@@ -21,6 +21,31 @@ __device__ unsigned long long g_reg_stamps[64];
 #define REG_BSTAMP(k_)
 #endif
 
+// Epilogue constants of a tile's BN columns (bias, and the time row when the tile lies in one image) are requested
+// BEFORE the operand loads and parked in LDS: the epilogue starts with a ds_read instead of a global round trip
+// (900 .. 1 200 of the 16 000 clocks of a 128 x 64 block at K = 320, in-kernel stamps).  Register-staged kernel: the first
+// BN / 4 threads load float4s and write bias + row to the stash after the first tiles have been requested.
+template <int BM, int BN>
+__device__ __forceinline__ bool cstash_request(const IgemmP& p, int m0, int n0, float4& cb, float4& cr) {
+    const int tid = threadIdx.x;
+    cb = make_float4(0.f, 0.f, 0.f, 0.f);
+    cr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.splitk != 1 || tid >= BN / 4) return false;
+    const int n = n0 + tid * 4 < p.N ? n0 + tid * 4 : p.N - 4;
+    if (p.bias) cb = *reinterpret_cast<const float4*>(p.bias + n);
+    if (p.rowvec) {
+        const int OHW = p.OH * p.OW;
+        int mlast = m0 + BM; if (mlast > p.M) mlast = p.M; mlast -= 1;
+        const int img0 = m0 / OHW;
+        if (mlast / OHW == img0) cr = *reinterpret_cast<const float4*>(p.rowvec + (size_t)img0 * p.ldrv + n);
+    }
+    return true;
+}
+__device__ __forceinline__ void cstash_park(bool on, float4 cb, float4 cr, float* cstash) {
+    if (on)   // published by the kernel's next barrier
+        *reinterpret_cast<float4*>(cstash + threadIdx.x * 4) = make_float4(cb.x + cr.x, cb.y + cr.y, cb.z + cr.z, cb.w + cr.w);
+}
+
 // ---- tile epilogue shared by the register-staged and the LDS-DMA kernels ----------------------------------------
 // lane holds pixel m (lane & 15), channels n .. n+3 (4 * (lane >> 4)) of each 16x16 sub-tile.
 // Optional fused GroupNorm statistics of the OUTPUT tensor: per-(image, channel) sum and sum of squares accumulated
@@ -29,7 +54,8 @@ __device__ unsigned long long g_reg_stamps[64];
 // no wave reads any more (the caller has passed a barrier since the last MFMA operand read).
 template <typename T, int BM, int BN>
 __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0,
-                                                    int z, float* red, float (&lns)[BM / 32], float (&lnq)[BM / 32]) {
+                                                    int z, float* red, float (&lns)[BM / 32], float (&lnq)[BM / 32],
+                                                    const float* cstash, const float* cstash_row) {
     constexpr int MI = BM / 32, NI = BN / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -43,7 +69,18 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc
     f32x4 cs[NI], cq[NI], add[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    if (p.splitk == 1) epilogue_consts<NI>(p, nb, one_image ? img0 : -1, add);
+    if (p.splitk == 1) {   // bias (+ the image's time row when one_image), parked in LDS during the prologue; cstash_row:
+                           // the LDS-DMA kernel parks the two rows separately (no adder on that path)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const float4 c = *reinterpret_cast<const float4*>(cstash + wn * (BN / 2) + fg * 4 + 16 * j);
+            add[j] = f32x4{c.x, c.y, c.z, c.w};
+            if (cstash_row) {
+                const float4 r = *reinterpret_cast<const float4*>(cstash_row + wn * (BN / 2) + fg * 4 + 16 * j);
+                add[j] += f32x4{r.x, r.y, r.z, r.w};
+            }
+        }
+    }
     if (p.ln_cs) {
         // folded LayerNorm: the lane's partial row sums cover the chunks it read (lane >> 4, + 4 per half tile); the four
         // lanes that share lane & 15 hold the rest of the row
@@ -81,30 +118,41 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc
             for (int j = 0; j < NI; ++j) acc[i][j] = (acc[i][j] - mean * csv[j]) * rstd;
         }
     }
+    REG_BSTAMP(8);
+    int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (BM / 2) + i * 16 + frow;
-        if (m >= p.M) continue;
-        if (p.splitk > 1) {
+        mrow[i] = m < p.M ? m : -1;
+    }
+    if (p.splitk > 1) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (mrow[i] < 0) continue;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const f32x4 v = acc[i][j];
                 if (nb + 16 * j < p.N)
-                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + m) * p.N + nb + 16 * j) =
+                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + mrow[i]) * p.N + nb + 16 * j) =
                         make_float4(v[0], v[1], v[2], v[3]);
             }
-        } else {
-            epilogue_row<T, NI>(p, m, nb, add, !one_image, acc[i]);
-            if (want_stats) {
+        }
+    } else {
+        epilogue_tile<T, MI, NI>(p, mrow, nb, add, !one_image, acc);
+        if (want_stats) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (mrow[i] < 0) continue;
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     if (nb + 16 * j >= p.N) continue;
                     if (one_image) { cs[j] += acc[i][j]; cq[j] += acc[i][j] * acc[i][j]; }
-                    else stats_add_elementwise(p, m, nb + 16 * j, acc[i][j]);
+                    else stats_add_elementwise(p, mrow[i], nb + 16 * j, acc[i][j]);
                 }
             }
         }
     }
+    REG_BSTAMP(9 + MI);
     if (want_stats && one_image) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -131,11 +179,13 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc
 
 template <typename T, int BM, int BN, int NST, bool LIN>   // LIN: the linear fast path, see igemm_glds_kernel
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_kernel(const IgemmP p) {
+    kernarg_touch<5>();
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;            // elements per K tile (128 B per row)
     constexpr int RA = BM / 32, RB = BN / 32;  // rows staged per thread
     constexpr int MI = BM / 32, NI = BN / 32;  // 16x16 sub-tiles per wave (wave tile BM/2 x BN/2)
     __shared__ __attribute__((aligned(16))) uint4 smem[2 * (BM + BN) * 8];
+    __shared__ __attribute__((aligned(16))) float cstash[BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     REG_BSTAMP(0);
@@ -260,9 +310,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
     // j = 1 .. NST-1; the loads of tile t + NST are issued before the MFMAs of tile t into the stage that held
     // tile t, and get NST MFMA phases to land (small grids have no co-resident block to hide the latency).
     REG_BSTAMP(1);
+    float4 cst_b, cst_r;
+    const bool cst_on = cstash_request<BM, BN>(p, m0, n0, cst_b, cst_r);
 #pragma unroll
     for (int u = 0; u < NST; ++u)
         if (kt0 + u < kt1) IGEMM_LOAD_TILE(kt0 + u, ra[u], rb[u]);
+    cstash_park(cst_on, cst_b, cst_r, cstash);
     if (kt0 < kt1) IGEMM_STORE_TILE(0, ra[0], rb[0]);
     __syncthreads();
 
@@ -306,7 +359,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
 #undef IGEMM_STORE_TILE
 
     REG_BSTAMP(3);
-    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(smem), lns, lnq);
+    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(smem), lns, lnq, cstash, nullptr);
     REG_BSTAMP(4);
 #ifdef GLDS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -336,6 +389,7 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() { GLDS_ASM("s_wa
 template <typename T, int BM, int BN, int NS, bool LIN>
 __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? (NS == 2 ? 2 : 1) : (NS == 3 && BM == 64 ? 3 : 2)) void igemm_glds_kernel(const IgemmP p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS address-space casts and gfx asm: device pass only (the host needs the stub)
+    kernarg_touch<5>();
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;
     constexpr int MI = BM / 32, NI = BN / 32;
@@ -346,6 +400,7 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? (NS == 2 ? 2 : 1) : (NS
     // it overlaps this block's MFMAs of tile t only -- for tiles whose two resident blocks cover each other (128 x 128)
     static_assert(NS >= 2 && NS <= 4 && ROWS % 32 == 0, "ring depth / tile shape");
     extern __shared__ __attribute__((aligned(16))) uint4 gsmem[];   // [NS][ROWS][8 x 16 B]
+    __shared__ __attribute__((aligned(16))) float cstash[2 * 256];   // two wave-wide DMA rows: bias, time row
     typedef __attribute__((address_space(3))) char lds_char;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -462,6 +517,26 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? (NS == 2 ? 2 : 1) : (NS
     const bool ln_on = p.ln_cs != nullptr;   // block-uniform
 
     GLDS_BSTAMP(1);
+    // Epilogue constants: wave 0 fetches the tile's bias row and (tile in one image) time row straight into the stash by
+    // LDS-DMA -- two more pieces, OLDER than every piece of the ring (loads retire in order: the ring's counted waits hold),
+    // no register and no compiler-visible LDS write (which would make the compiler drain the ring).  Lanes past column
+    // N, and absent rows (zero-sized descriptor), deliver zeros.
+    if (p.splitk == 1 && wave == 0) {
+        const unsigned nbytes = p.N > n0 ? (unsigned)(p.N - n0) * 4u : 0u;
+        const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.bias ? p.bias + n0 : (const float*)p.w), 0, p.bias ? nbytes : 0u, 0x00020000);
+        const float* rowp = nullptr;
+        if (p.rowvec) {
+            int mlast = m0 + BM; if (mlast > p.M) mlast = p.M; mlast -= 1;
+            const int img0 = m0 / OHW;
+            if (mlast / OHW == img0) rowp = p.rowvec + (size_t)img0 * p.ldrv + n0;
+        }
+        const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(rowp ? rowp : (const float*)p.w), 0, rowp ? nbytes : 0u, 0x00020000);
+        const unsigned off = lane < BN / 4 ? (unsigned)lane * 16u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_char*)cstash, 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsr, (lds_char*)cstash + 1024, 16, off, 0, 0, 0);
+    }
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (u < nt) GLDS_LOAD_TILE(kt0 + u, u);
@@ -548,7 +623,7 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? (NS == 2 ? 2 : 1) : (NS
 #undef GLDS_LOAD_TILE
     GLDS_BSTAMP(3);
     __syncthreads();   // every wave is done with the last tile: the LDS becomes the statistics scratch
-    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(gsmem), lns, lnq);
+    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(gsmem), lns, lnq, cstash, cstash + 256);
     GLDS_BSTAMP(4);
 #endif
 }

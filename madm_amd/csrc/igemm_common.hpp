@@ -142,18 +142,42 @@ __device__ __forceinline__ f32x4 epilogue_store(const IgemmP& p, int m, int n, f
 // clocks of a 128 x 128 tile's epilogue (in-kernel stamps, tools/exp/stamps_block.py).
 template <int NI>
 __device__ __forceinline__ void epilogue_consts(const IgemmP& p, int nb, int img, f32x4 (&add)[NI]) {
+    // no per-lane condition around the loads (a lane past column N reads the last valid chunk instead -- its values are
+    // never stored nor counted): behind exec masks every load got a vmcnt(0) of its own, NI dependent round trips
+#pragma unroll
+    for (int j = 0; j < NI; ++j) add[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        float4 b[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = nb + 16 * j < p.N ? nb + 16 * j : p.N - 4;
+            b[j] = *reinterpret_cast<const float4*>(p.bias + n);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) add[j] = f32x4{b[j].x, b[j].y, b[j].z, b[j].w};
+    }
+    if (p.rowvec && img >= 0) {
+        float4 t[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = nb + 16 * j < p.N ? nb + 16 * j : p.N - 4;
+            t[j] = *reinterpret_cast<const float4*>(p.rowvec + (size_t)img * p.ldrv + n);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { add[j][0] += t[j].x; add[j][1] += t[j].y; add[j][2] += t[j].z; add[j][3] += t[j].w; }
+    }
+    // The constants must have LANDED before the first output store is issued.  gfx950 counts loads and stores in one
+    // vmcnt and they retire out of order with respect to each other, so once a store is in flight the compiler can only
+    // wait for an older load with vmcnt(0) -- which also waits for every store.  The loads above sit behind per-column
+    // conditions, so without this the "still pending" state survived into the row loop and EVERY row began with a
+    // vmcnt(0) behind the previous row's stores: 1 000 .. 1 400 clocks per row, 5 500 of the 18 000 clocks of a
+    // 128 x 64 block at K = 320 (in-kernel stamps, tools/exp/stamps_reg.py, round 4).  The empty asm makes the values
+    // register-defined here, unconditionally.
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        add[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (nb + 16 * j >= p.N) continue;
-        if (p.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + nb + 16 * j);
-            add[j] = f32x4{b.x, b.y, b.z, b.w};
-        }
-        if (p.rowvec && img >= 0) {
-            const float4 t = *reinterpret_cast<const float4*>(p.rowvec + (size_t)img * p.ldrv + nb + 16 * j);
-            add[j][0] += t.x; add[j][1] += t.y; add[j][2] += t.z; add[j][3] += t.w;
-        }
+        float a0 = add[j][0], a1 = add[j][1], a2 = add[j][2], a3 = add[j][3];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        add[j] = f32x4{a0, a1, a2, a3};
     }
 }
 
@@ -229,6 +253,83 @@ __device__ __forceinline__ void epilogue_row(const IgemmP& p, int m, int nb, con
 #pragma unroll
         for (int j = 0; j < NI; ++j)
             if (nb + 16 * j < p.N) store4<T>(op + 16 * j, v[j]);
+    }
+}
+
+// The MI x NI sub-tiles of one wave: constants, residual, activation for ALL rows first, then all the stores back to
+// back -- no load (and so no vmcnt(0), see epilogue_consts) between two stores; the residual pieces of all rows are in
+// flight together.  mrow[i] = output row of sub-tile row i or -1 (outside the tensor).  Same operation order per element
+// as epilogue_row ((acc + constants) + residual, activation): bit-identical results.  Tiles that straddle images with
+// a time row (img_rows) keep the row-by-row form.  acc returns the stored values (fused statistics).
+template <typename T, int MI, int NI>
+__device__ __forceinline__ void epilogue_tile(const IgemmP& p, const int (&mrow)[MI], int nb, const f32x4 (&add)[NI],
+                                              bool img_rows, f32x4 (&acc)[MI][NI]) {
+    if ((p.rowvec && img_rows) || (p.epilogue == MADM_EPI_GEGLU && p.residual)) {   // block-uniform, rare
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            if (mrow[i] >= 0) epilogue_row<T, NI>(p, mrow[i], nb, add, img_rows, acc[i]);
+        return;
+    }
+    if (p.epilogue == MADM_EPI_GEGLU) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const f32x4 t = acc[i][j] + add[j];
+                acc[i][j] = f32x4{t[0] * gelu_erf_f(t[1]), t[2] * gelu_erf_f(t[3]), 0.f, 0.f};
+            }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (mrow[i] < 0) continue;
+            T* op = reinterpret_cast<T*>(p.out) + (size_t)mrow[i] * p.ldo + (nb >> 1);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (nb + 16 * j < p.N) store2<T>(op + 8 * j, acc[i][j][0], acc[i][j][1]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] += add[j];
+    if (p.residual) {
+        // unconditional loads (rows / columns outside the tensor read a valid element instead; their sums are neither
+        // stored nor counted): all MI x NI pieces in flight together, one wait
+        f32x4 r[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const T* rp = reinterpret_cast<const T*>(p.residual) + (size_t)(mrow[i] < 0 ? 0 : mrow[i]) * p.ldr;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) r[i][j] = load4<T>(rp + (nb + 16 * j < p.N ? nb + 16 * j : p.N - 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] += r[i][j];
+    }
+    if (p.epilogue == MADM_EPI_RELU) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                f32x4& v = acc[i][j];
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        if (mrow[i] < 0) continue;
+        if (p.out_f32) {
+            float* op = reinterpret_cast<float*>(p.out) + (size_t)mrow[i] * p.ldo + nb;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (nb + 16 * j < p.N) store4<float>(op + 16 * j, acc[i][j]);
+        } else {
+            T* op = reinterpret_cast<T*>(p.out) + (size_t)mrow[i] * p.ldo + nb;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                if (nb + 16 * j < p.N) store4<T>(op + 16 * j, acc[i][j]);
+        }
     }
 }
 
