@@ -26,24 +26,38 @@ __device__ unsigned long long g_reg_stamps[64];
 // (900 .. 1 200 of the 16 000 clocks of a 128 x 64 block at K = 320, in-kernel stamps).  Register-staged kernel: the first
 // BN / 4 threads load float4s and write bias + row to the stash after the first tiles have been requested.
 template <int BM, int BN>
-__device__ __forceinline__ bool cstash_request(const IgemmP& p, int m0, int n0, float4& cb, float4& cr) {
+__device__ __forceinline__ bool cstash_request(const IgemmP& p, int m0, int n0, u32x4& cb, u32x4& cr, u32x4& cl) {
+    // buffer loads like the operand tiles' (ONE kind of memory operation in flight: the compiler can wait for these three
+    // with a counted vmcnt instead of draining the tiles behind them); absent rows = zero-sized descriptors, lanes past
+    // column N / past the first BN / 4 threads = out-of-range offsets: zeros, no branches
+    constexpr unsigned OOB = 0x80000000u;
     const int tid = threadIdx.x;
-    cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    cr = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.splitk != 1 || tid >= BN / 4) return false;
-    const int n = n0 + tid * 4 < p.N ? n0 + tid * 4 : p.N - 4;
-    if (p.bias) cb = *reinterpret_cast<const float4*>(p.bias + n);
+    const bool on = p.splitk == 1 && tid < BN / 4;
+    const unsigned nbytes = (unsigned)p.N * 4u;
+    const float* rowp = nullptr;
     if (p.rowvec) {
         const int OHW = p.OH * p.OW;
         int mlast = m0 + BM; if (mlast > p.M) mlast = p.M; mlast -= 1;
         const int img0 = m0 / OHW;
-        if (mlast / OHW == img0) cr = *reinterpret_cast<const float4*>(p.rowvec + (size_t)img0 * p.ldrv + n);
+        if (mlast / OHW == img0) rowp = p.rowvec + (size_t)img0 * p.ldrv;
     }
-    return true;
+    const float* dummy = reinterpret_cast<const float*>(p.w);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? p.bias : dummy), 0, p.bias ? nbytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(rowp ? rowp : dummy), 0, rowp ? nbytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ln_cs ? p.ln_cs : dummy), 0, p.ln_cs ? nbytes : 0u, 0x00020000);
+    const unsigned off = on ? (unsigned)(n0 + tid * 4) * 4u : OOB;
+    cb = __builtin_amdgcn_raw_buffer_load_b128(rb, off, 0, 0);
+    cr = __builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, 0);
+    cl = __builtin_amdgcn_raw_buffer_load_b128(rl, off, 0, 0);   // folded LayerNorm: column sums of the weight
+    return on;
 }
-__device__ __forceinline__ void cstash_park(bool on, float4 cb, float4 cr, float* cstash) {
-    if (on)   // published by the kernel's next barrier
+template <int BN>
+__device__ __forceinline__ void cstash_park(bool on, u32x4 cb_, u32x4 cr_, u32x4 cl_, float* cstash) {
+    if (on) {   // published by the kernel's next barrier
+        const float4 cb = __builtin_bit_cast(float4, cb_), cr = __builtin_bit_cast(float4, cr_);
         *reinterpret_cast<float4*>(cstash + threadIdx.x * 4) = make_float4(cb.x + cr.x, cb.y + cr.y, cb.z + cr.z, cb.w + cr.w);
+        *reinterpret_cast<float4*>(cstash + BN + threadIdx.x * 4) = __builtin_bit_cast(float4, cl_);
+    }
 }
 
 // ---- tile epilogue shared by the register-staged and the LDS-DMA kernels ----------------------------------------
@@ -55,7 +69,7 @@ __device__ __forceinline__ void cstash_park(bool on, float4 cb, float4 cr, float
 template <typename T, int BM, int BN>
 __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0,
                                                     int z, float* red, float (&lns)[BM / 32], float (&lnq)[BM / 32],
-                                                    const float* cstash, const float* cstash_row) {
+                                                    const float* cstash, const float* cstash_row, const float* cstash_ln) {
     constexpr int MI = BM / 32, NI = BN / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -86,12 +100,9 @@ __device__ __forceinline__ void igemm_tile_epilogue(const IgemmP& p, f32x4 (&acc
         // lanes that share lane & 15 hold the rest of the row
         f32x4 csv[NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            csv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (nb + 16 * j < p.N) {
-                const float4 c = *reinterpret_cast<const float4*>(p.ln_cs + nb + 16 * j);
-                csv[j] = f32x4{c.x, c.y, c.z, c.w};
-            }
+        for (int j = 0; j < NI; ++j) {   // parked in LDS with the other epilogue constants
+            const float4 c = *reinterpret_cast<const float4*>(cstash_ln + wn * (BN / 2) + fg * 4 + 16 * j);
+            csv[j] = f32x4{c.x, c.y, c.z, c.w};
         }
         const float inv_k = 1.0f / (float)p.K;
         // each of the two waves that own these rows (wn = 0 / 1) summed one K half of every tile: exchange through LDS
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
     constexpr int RA = BM / 32, RB = BN / 32;  // rows staged per thread
     constexpr int MI = BM / 32, NI = BN / 32;  // 16x16 sub-tiles per wave (wave tile BM/2 x BN/2)
     __shared__ __attribute__((aligned(16))) uint4 smem[2 * (BM + BN) * 8];
-    __shared__ __attribute__((aligned(16))) float cstash[BN];
+    __shared__ __attribute__((aligned(16))) float cstash[2 * BN];   // [bias + time row | LayerNorm column sums]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     REG_BSTAMP(0);
@@ -310,12 +321,12 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
     // j = 1 .. NST-1; the loads of tile t + NST are issued before the MFMAs of tile t into the stage that held
     // tile t, and get NST MFMA phases to land (small grids have no co-resident block to hide the latency).
     REG_BSTAMP(1);
-    float4 cst_b, cst_r;
-    const bool cst_on = cstash_request<BM, BN>(p, m0, n0, cst_b, cst_r);
+    u32x4 cst_b, cst_r, cst_l;
+    const bool cst_on = cstash_request<BM, BN>(p, m0, n0, cst_b, cst_r, cst_l);
 #pragma unroll
     for (int u = 0; u < NST; ++u)
         if (kt0 + u < kt1) IGEMM_LOAD_TILE(kt0 + u, ra[u], rb[u]);
-    cstash_park(cst_on, cst_b, cst_r, cstash);
+    cstash_park<BN>(cst_on, cst_b, cst_r, cst_l, cstash);
     if (kt0 < kt1) IGEMM_STORE_TILE(0, ra[0], rb[0]);
     __syncthreads();
 
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void igemm_ker
 #undef IGEMM_STORE_TILE
 
     REG_BSTAMP(3);
-    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(smem), lns, lnq, cstash, nullptr);
+    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(smem), lns, lnq, cstash, nullptr, cstash + BN);
     REG_BSTAMP(4);
 #ifdef GLDS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? (NS == 2 ? 2 : 1) : (NS
     // it overlaps this block's MFMAs of tile t only -- for tiles whose two resident blocks cover each other (128 x 128)
     static_assert(NS >= 2 && NS <= 4 && ROWS % 32 == 0, "ring depth / tile shape");
     extern __shared__ __attribute__((aligned(16))) uint4 gsmem[];   // [NS][ROWS][8 x 16 B]
-    __shared__ __attribute__((aligned(16))) float cstash[2 * 256];   // two wave-wide DMA rows: bias, time row
+    __shared__ __attribute__((aligned(16))) float cstash[3 * 256];   // three wave-wide DMA rows: bias, time row, LayerNorm column sums
     typedef __attribute__((address_space(3))) char lds_char;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -517,8 +528,8 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? (NS == 2 ? 2 : 1) : (NS
     const bool ln_on = p.ln_cs != nullptr;   // block-uniform
 
     GLDS_BSTAMP(1);
-    // Epilogue constants: wave 0 fetches the tile's bias row and (tile in one image) time row straight into the stash by
-    // LDS-DMA -- two more pieces, OLDER than every piece of the ring (loads retire in order: the ring's counted waits hold),
+    // Epilogue constants: wave 0 fetches the tile's bias row, (tile in one image) time row and LayerNorm column sums straight
+    // into the stash by LDS-DMA -- three more pieces, OLDER than every piece of the ring (loads retire in order: the ring's counted waits hold),
     // no register and no compiler-visible LDS write (which would make the compiler drain the ring).  Lanes past column
     // N, and absent rows (zero-sized descriptor), deliver zeros.
     if (p.splitk == 1 && wave == 0) {
@@ -536,6 +547,9 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? (NS == 2 ? 2 : 1) : (NS
         const unsigned off = lane < BN / 4 ? (unsigned)lane * 16u : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_char*)cstash, 16, off, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsr, (lds_char*)cstash + 1024, 16, off, 0, 0, 0);
+        const __amdgpu_buffer_rsrc_t rsl = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.ln_cs ? p.ln_cs + n0 : (const float*)p.w), 0, p.ln_cs ? nbytes : 0u, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsl, (lds_char*)cstash + 2048, 16, off, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
@@ -623,7 +637,7 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? (NS == 2 ? 2 : 1) : (NS
 #undef GLDS_LOAD_TILE
     GLDS_BSTAMP(3);
     __syncthreads();   // every wave is done with the last tile: the LDS becomes the statistics scratch
-    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(gsmem), lns, lnq, cstash, cstash + 256);
+    igemm_tile_epilogue<T, BM, BN>(p, acc, m0, n0, z, reinterpret_cast<float*>(gsmem), lns, lnq, cstash, cstash + 256, cstash + 512);
     GLDS_BSTAMP(4);
 #endif
 }
