@@ -186,6 +186,117 @@ __global__ __launch_bounds__(256) void dwconv3x3_comb_kernel(const T* __restrict
     }
 }
 
+// The dilated conv seen on its own lattice: the pixels (ry + d i, rx + d j) of one residue class form a dense
+// ceil(H / d) x ceil(W / d) image on which the conv is a plain 3x3.  A workgroup takes a tile of at most 16 x 16 outputs
+// of one residue class and one 128-byte channel slab (8 x 16-byte chunks), stages the (th + 2) x (tw + 2) halo in LDS
+// -- every pixel of it one full 128-byte line -- and each thread forms 8 horizontally adjacent outputs of one chunk
+// from 3 x 10 LDS reads: 1.27 global requests per input element instead of the comb kernel's 4.5 (which all went
+// through the L1 / L2 path: 390 .. 430 us for the head's 0.5 GB tensor against 200 us of HBM time).  Taps in the order
+// of the other two kernels (row-major, fused multiply-add): identical bits.  grid.x = slab fastest, then tile, residue,
+// image: the 16 slabs of a pixel (2 KB at C = 1024) are requested by neighbouring workgroups at about the same time.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_lattice_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                T* __restrict__ y, int ldy, int B, int H, int W, int C, int dil,
+                                                                int act, int ny, int nx, int th, int tw) {
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int CHS = 8 * EPC;                       // channels per slab (128 bytes)
+    __shared__ __attribute__((aligned(16))) uint4 halo[18 * 18 * 8];
+    __shared__ __attribute__((aligned(16))) float wl[11 * CHS];   // 9 taps, scale, shift of the slab's channels
+    const int tid = threadIdx.x;
+    unsigned t = blockIdx.x;
+    const int slabs = C / CHS;
+    const int slab = (int)(t % (unsigned)slabs); t /= (unsigned)slabs;
+    const int tx = (int)(t % (unsigned)nx); t /= (unsigned)nx;
+    const int ty = (int)(t % (unsigned)ny); t /= (unsigned)ny;
+    const int rx = (int)(t % (unsigned)dil); t /= (unsigned)dil;
+    const int ry = (int)(t % (unsigned)dil);
+    const int b = (int)(t / (unsigned)dil);
+    const int c0 = slab * CHS;
+    const int sy0 = ty * th, sx0 = tx * tw;            // first lattice row / column of the tile
+    const int hw_ = tw + 2, items = (th + 2) * hw_ * 8;
+    // ---- halo: all of a thread's pieces requested before the first is written ----
+    constexpr int MAXP = (18 * 18 * 8 + 255) / 256;    // 11
+    uint4 hv[MAXP];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int i = tid + 256 * k;
+        hv[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < items) {
+            const int hp = i >> 3, q = i & 7;
+            const int hy = hp / hw_, hx = hp - hy * hw_;
+            const int iy = ry + dil * (sy0 + hy - 1), ix = rx + dil * (sx0 + hx - 1);
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                hv[k] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + c0 + q * EPC);
+        }
+    }
+    float4 wv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const int row = tid / (CHS / 4), col = (tid % (CHS / 4)) * 4;
+        const float* src = row < 9 ? w + (size_t)row * C : (row == 9 ? scale : shift);
+        if (row < 11) wv4 = *reinterpret_cast<const float4*>(src + c0 + col);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int i = tid + 256 * k;
+        if (i < items) halo[i] = hv[k];
+    }
+    if (tid < 11 * CHS / 4) *reinterpret_cast<float4*>(wl + tid * 4) = wv4;
+    __syncthreads();
+    // ---- 8 outputs of one chunk per thread: row r of the tile, columns half * 8 .. + 7 ----
+    const int q = tid & 7, g = tid >> 3;
+    const int r = g >> 1, half = g & 1;
+    const int oy = ry + dil * (sy0 + r);
+    if (r >= th || half * 8 >= tw || oy >= H) return;
+    float acc[8][EPC];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) acc[o][j] = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const int iy = oy + (rr - 1) * dil;
+        if ((unsigned)iy < (unsigned)H) {              // (taps outside the image are skipped, as in the other kernels)
+        float wt[3][EPC];
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) wt[s_][j] = wl[(rr * 3 + s_) * CHS + q * EPC + j];
+        const uint4* hrow = halo + ((r + rr) * hw_ + half * 8) * 8 + q;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {                 // halo column half * 8 + c feeds outputs c - 2, c - 1, c
+            // (no break / continue in here: the loop must unroll completely, acc[] is indexed by c - s)
+            const int ix = rx + dil * (sx0 + half * 8 + c - 1);
+            if (half * 8 + c < hw_ && (unsigned)ix < (unsigned)W) {
+                float f[EPC];
+                chunk_to_f32<T>(hrow[c * 8], f);
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    if (c - s_ >= 0 && c - s_ < 8) {
+#pragma unroll
+                        for (int j = 0; j < EPC; ++j) acc[c - s_][j] += f[j] * wt[s_][j];
+                    }
+                }
+            }
+        }
+        }
+    }
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) { sc[j] = wl[9 * CHS + q * EPC + j]; sh[j] = wl[10 * CHS + q * EPC + j]; }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+        const int sx = half * 8 + o;
+        const int ox = rx + dil * (sx0 + sx);
+        if (sx < tw && ox < W) {
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) acc[o][j] = acc[o][j] * sc[j] + sh[j];
+            act_inplace<EPC>(acc[o], act);
+            *reinterpret_cast<uint4*>(y + (((size_t)b * H + oy) * W + ox) * ldy + c0 + q * EPC) = f32_to_chunk<T>(acc[o]);
+        }
+    }
+}
+
 // out[pl][y][x] = in[pl][y1 + y][x1 + x] * scale inside the input, 0 outside: zero padding, cropping, windows
 __global__ void scale_pad_crop_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int IH, int IW,
                                       int y1, int x1, int OH, int OW, float scale) {
@@ -321,9 +432,26 @@ int madm_dwconv3x3(int dtype, const void* x, const float* w, const float* scale,
     const size_t total = (size_t)B * H * W * (C / epc);
     MADM_REQUIRE(total < 0x7fffffffull, "dwconv3x3: tensor too large for 32-bit indexing");
     hipStream_t s = (hipStream_t)stream;
-    // MADM_DWCONV_KERNEL (tests, A/B runs): 0 / unset = choose, 1 = plain, 2 = comb, 3 = comb with per-XCD channel slabs
+    // MADM_DWCONV_KERNEL (tests, A/B runs): 0 / unset = choose, 1 = plain, 2 = comb, 3 = comb with per-XCD channel slabs, 4 = lattice
     const char* fe = getenv("MADM_DWCONV_KERNEL");
     const int force = fe ? atoi(fe) : 0;
+    // 4 = the lattice kernel (one residue class of the dilation per workgroup, halo in LDS): large maps with whole
+    // 128-byte channel slabs
+    {
+        const int chs = 8 * epc;
+        const int shmax = (H + dilation - 1) / dilation, swmax = (W + dilation - 1) / dilation;
+        const bool fits = C % chs == 0 && dilation > 1;
+        const bool pays = total >= ((size_t)1 << 21) && shmax >= 8 && swmax >= 8;
+        if (fits && (force == 4 || (force == 0 && pays))) {
+            const int ny = (shmax + 15) / 16, nx = (swmax + 15) / 16;
+            const int th = (shmax + ny - 1) / ny, tw = (swmax + nx - 1) / nx;
+            const size_t blocks = (size_t)B * dilation * dilation * ny * nx * (C / chs);
+            MADM_REQUIRE(blocks < 0x7fffffffull, "dwconv3x3: grid too large");
+            MADM_DISPATCH_DTYPE(dtype, (dwconv3x3_lattice_kernel<T><<<(unsigned)blocks, 256, 0, s>>>(
+                                           (const T*)x, w, scale, shift, (T*)y, ldy, B, H, W, C, dilation, act, ny, nx, th, tw)));
+            return madm_check_launch("dwconv3x3_lattice_kernel");
+        }
+    }
     if (force != 1 && W >= 4 * dilation) {
         constexpr int PX = 4;
         const int kmax = (W + dilation - 1) / dilation;                  // outputs per residue class (upper bound)

@@ -107,6 +107,104 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
     for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) unsafeAtomicAdd(dw + i, lds[i]);
 }
 
+// The same gradient on the dilation's lattice (spatial.hip, dwconv3x3_lattice_kernel): a workgroup owns one residue
+// class (ry, rx) of one image and one 128-byte channel slab and walks that class's tiles of at most 16 x 16 lattice
+// pixels; per tile the x halo sits in LDS (1.27 global requests per element instead of 9), every thread multiplies its 8
+// dy chunks with the 3 x 10 halo chunks around them into 9 x EPC register sums that live across the tiles; one LDS +
+// global atomic round per workgroup (measurements at the launcher).
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_lattice_kernel(const T* __restrict__ x, const T* __restrict__ dy, int lddy,
+                                                                      float* __restrict__ dw, int B, int H, int W, int C, int dil,
+                                                                      int ny, int nx, int th, int tw) {
+    constexpr int EPC = TT<T>::EPC;
+    constexpr int CHS = 8 * EPC;
+    __shared__ __attribute__((aligned(16))) uint4 halo[18 * 18 * 8];
+    __shared__ float red[9 * CHS];
+    const int tid = threadIdx.x;
+    unsigned t = blockIdx.x;
+    const int slabs = C / CHS;
+    const int slab = (int)(t % (unsigned)slabs); t /= (unsigned)slabs;
+    const int rx = (int)(t % (unsigned)dil); t /= (unsigned)dil;
+    const int ry = (int)(t % (unsigned)dil);
+    const int b = (int)(t / (unsigned)dil);
+    const int c0 = slab * CHS;
+    const int hw_ = tw + 2, items = (th + 2) * hw_ * 8;
+    const int q = tid & 7, g = tid >> 3;
+    const int r = g >> 1, half = g & 1;
+    for (int i = tid; i < 9 * CHS; i += 256) red[i] = 0.f;
+    float acc[9][EPC];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) acc[k][j] = 0.f;
+    constexpr int MAXP = (18 * 18 * 8 + 255) / 256;
+    for (int tile = 0; tile < ny * nx; ++tile) {
+        const int ty = tile / nx, tx = tile - ty * nx;
+        const int sy0 = ty * th, sx0 = tx * tw;
+        uint4 hv[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int i = tid + 256 * k;
+            hv[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < items) {
+                const int hp = i >> 3, qq = i & 7;
+                const int hy = hp / hw_, hx = hp - hy * hw_;
+                const int iy = ry + dil * (sy0 + hy - 1), ix = rx + dil * (sx0 + hx - 1);
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    hv[k] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + iy) * W + ix) * C + c0 + qq * EPC);
+            }
+        }
+        // the thread's 8 dy chunks: row r of the tile, columns half * 8 .. + 7 (zeros outside the tile / the image)
+        const int oy = ry + dil * (sy0 + r);
+        const bool row_on = r < th && oy < H;
+        uint4 dv[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int sx = half * 8 + o;
+            const int ox = rx + dil * (sx0 + sx);
+            dv[o] = make_uint4(0u, 0u, 0u, 0u);
+            if (row_on && sx < tw && ox < W)
+                dv[o] = *reinterpret_cast<const uint4*>(dy + (((size_t)b * H + oy) * W + ox) * lddy + c0 + q * EPC);
+        }
+        __syncthreads();   // the previous tile's halo has been read by every wave
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const int i = tid + 256 * k;
+            if (i < items) halo[i] = hv[k];
+        }
+        __syncthreads();
+        if (row_on) {
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+                const uint4* hrow = halo + ((r + rr) * hw_ + half * 8) * 8 + q;
+#pragma unroll
+                for (int c = 0; c < 10; ++c) {      // halo column half * 8 + c meets outputs c - s under tap (rr, s)
+                    if (half * 8 + c < hw_) {       // (pixels outside the image hold zeros in the halo)
+                        float f[EPC];
+                        chunk_to_f32<T>(hrow[c * 8], f);
+#pragma unroll
+                        for (int s_ = 0; s_ < 3; ++s_) {
+                            if (c - s_ >= 0 && c - s_ < 8) {
+                                float d[EPC];
+                                chunk_to_f32<T>(dv[c - s_], d);
+#pragma unroll
+                                for (int j = 0; j < EPC; ++j) acc[rr * 3 + s_][j] += d[j] * f[j];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) atomicAdd(&red[k * CHS + q * EPC + j], acc[k][j]);
+    __syncthreads();
+    for (int i = tid; i < 9 * CHS; i += 256) unsafeAtomicAdd(dw + (size_t)(i / CHS) * C + c0 + (i % CHS), red[i]);
+}
+
 // adjoint of the 1-D bilinear resize along one axis of a [outer][L][inner] tensor:
 //   out[o][i][r] = sum_l w(l -> i) * in[o][l][r],   l over the Lout positions whose interpolation reads source i.
 // IN_T / OUT_T: the side stored as T (16-byte chunks of EPC elements), the other side is f32.  Two passes (x, then y)
@@ -413,13 +511,33 @@ int madm_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, int lddy, flo
     MADM_REQUIRE(x && dy && dw && B > 0 && H > 0 && W > 0 && C > 0 && dilation > 0, "dwconv3x3_wgrad: bad argument");
     const int epc = madm_epc(dtype);
     MADM_REQUIRE(C % epc == 0 && lddy % epc == 0 && lddy >= C, "dwconv3x3_wgrad: C / lddy must be multiples of %d", epc);
+    hipStream_t s = (hipStream_t)stream;
+    {   // large maps with whole 128-byte channel slabs: the lattice kernel (MADM_DWCONV_KERNEL=4 forces it, =1 forbids it)
+        const char* fe = getenv("MADM_DWCONV_KERNEL");
+        const int force = fe ? atoi(fe) : 0;
+        const int chs = 8 * epc;
+        const int shmax = (H + dilation - 1) / dilation, swmax = (W + dilation - 1) / dilation;
+        const bool fits = C % chs == 0 && dilation > 1;
+        const int ny = (shmax + 15) / 16, nx = (swmax + 15) / 16;
+        // a workgroup walks the ny * nx tiles of its class one after the other (load, barrier, multiply): with few tiles
+        // per class nothing covers the loads -- head tensor, 2 x 512 x 512 x 1024: 1 415 -> 709 us at dilation 6 (36
+        // tiles), 1 355 -> 905 at 12 (9), 1 388 -> 1 461 at 18 (4)
+        const bool pays = (size_t)B * H * W * (C / epc) >= ((size_t)1 << 21) && ny * nx >= 9;
+        if (fits && (force == 4 || (force == 0 && pays))) {
+            const int th = (shmax + ny - 1) / ny, tw = (swmax + nx - 1) / nx;
+            const size_t blocks = (size_t)B * dilation * dilation * (C / chs);
+            MADM_REQUIRE(blocks < 0x7fffffffull, "dwconv3x3_wgrad: grid too large");
+            MADM_DISPATCH_DTYPE(dtype, (dwconv3x3_wgrad_lattice_kernel<T><<<(unsigned)blocks, 256, 0, s>>>(
+                                           (const T*)x, (const T*)dy, lddy, dw, B, H, W, C, dilation, ny, nx, th, tw)));
+            return madm_check_launch("dwconv3x3_wgrad_lattice_kernel");
+        }
+    }
     const size_t shm = (size_t)9 * C * sizeof(float);
     MADM_REQUIRE(shm <= 64 * 1024, "dwconv3x3_wgrad: C = %d too large", C);
     const size_t npix = (size_t)B * H * W;
     int ppb = (int)((npix + 2047) / 2048);
     if (ppb < 64) ppb = 64;
     const unsigned blocks = (unsigned)((npix + ppb - 1) / ppb);
-    hipStream_t s = (hipStream_t)stream;
     MADM_DISPATCH_DTYPE(dtype, (dwconv3x3_wgrad_kernel<T><<<blocks, 256, shm, s>>>((const T*)x, (const T*)dy, lddy, dw, B, H,
                                                                                  W, C, dilation, ppb)));
     return madm_check_launch("dwconv3x3_wgrad_kernel");

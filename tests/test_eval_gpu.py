@@ -61,7 +61,7 @@ def test_spatial_kernels(cuda, dtype):
                       out=buf[:, C:2 * C])
         assert rel_err(from_tokens(buf[:, C:2 * C], 2, 21, 77), ref)[0] < (1e-6 if dtype == torch.float32 else 8e-3), dil
         assert buf[:, :C].abs().max().item() == 0 and buf[:, 2 * C:].abs().max().item() == 0
-    # the comb kernel with per-XCD channel slabs (large tensors; forced here): the three variants accumulate in the same
+    # the comb kernel with per-XCD channel slabs and the lattice kernel (large tensors; forced here): all variants accumulate in the same
     # order -> identical bits; ragged sizes, column window, every dilation
     import os
     C2 = 128
@@ -71,7 +71,7 @@ def test_spatial_kernels(cuda, dtype):
     for dil in (1, 6, 12, 18):
         ref = F.relu(F.conv2d(xc, w2, None, padding=dil, dilation=dil, groups=C2) * s2[None, :, None, None] + t2[None, :, None, None])
         outs = []
-        for kern in ("1", "2", "3"):
+        for kern in ("1", "2", "3", "4"):   # 4 = the lattice kernel (one residue class of the dilation per workgroup)
             os.environ["MADM_DWCONV_KERNEL"] = kern
             try:
                 buf = torch.zeros((2 * 35 * 83, 3 * C2), dtype=dtype, device="cuda")
@@ -82,7 +82,7 @@ def test_spatial_kernels(cuda, dtype):
             assert rel_err(from_tokens(buf[:, C2:2 * C2], 2, 35, 83), ref)[0] < (1e-6 if dtype == torch.float32 else 8e-3), (dil, kern)
             assert buf[:, :C2].abs().max().item() == 0 and buf[:, 2 * C2:].abs().max().item() == 0
             outs.append(buf)
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), dil
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3]), dil
     # tanh gates (prompt / time conditioning) with the batch repeat
     a1, x1, a2, x2 = torch.rand(1, 77, 768), _gen((1, 77, 768), 7), torch.rand(1, 77, 768), _gen((1, 77, 768), 8)
     g = ops.tanh_gate(x1.cuda(), a1.cuda(), x2.cuda(), a2.cuda(), repeat=3).cpu()

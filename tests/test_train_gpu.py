@@ -87,6 +87,27 @@ def test_dropout_relu_dwconv_grad_kernels(cuda, dtype):
     one, zero = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
     dx = ops.dwconv3x3(dyt, w9c.flip(0).contiguous(), one, zero, B, H, W, dil, 0)
     assert rel_err(from_tokens(dx, B, H, W), xr.grad)[0] < _tol(dtype, 1e-5, 8e-3, 1e-3)
+    # the lattice kernels (one residue class of the dilation per workgroup; chosen for the head's 512 x 512 x 1024 tensors,
+    # forced here): ragged maps with more than one tile per class, every dilation of the head, a row-strided dy window
+    import os
+    C2, H2, W2 = 128, 37, 83
+    x2 = _q(torch.randn((B, C2, H2, W2), generator=g), dtype)
+    dy2 = _q(torch.randn((B, C2, H2, W2), generator=g), dtype)
+    w2 = torch.randn((C2, 1, 3, 3), generator=g) / 3
+    wide = torch.zeros((B * H2 * W2, 3 * C2), dtype=dtype, device="cuda")
+    wide[:, C2:2 * C2] = to_tokens(dy2, dtype)
+    for d2 in (2, 6, 12, 18):
+        xr2, wr2 = x2.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+        F.conv2d(xr2, wr2, padding=d2, dilation=d2, groups=C2).backward(dy2)
+        os.environ["MADM_DWCONV_KERNEL"] = "4"
+        try:
+            dw2 = ops.dwconv3x3_wgrad(to_tokens(x2, dtype), wide[:, C2:2 * C2], B, H2, W2, d2)
+            dx2 = ops.dwconv3x3(to_tokens(dy2, dtype), w2.reshape(C2, 9).t().contiguous().cuda().flip(0).contiguous(),
+                                torch.ones(C2, device="cuda"), torch.zeros(C2, device="cuda"), B, H2, W2, d2, 0)
+        finally:
+            del os.environ["MADM_DWCONV_KERNEL"]
+        assert rel_err(dw2.t().reshape(C2, 1, 3, 3).cpu(), wr2.grad)[0] < _tol(dtype, 2e-5, 2e-5, 2e-5), d2
+        assert rel_err(from_tokens(dx2, B, H2, W2), xr2.grad)[0] < _tol(dtype, 1e-5, 8e-3, 1e-3), d2
 
 
 @pytest.mark.parametrize("dtype", DT, ids=IDS)
