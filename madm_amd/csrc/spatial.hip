@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_comb_kernel(const T* __restrict
 }
 
 // The dilated conv seen on its own lattice: the pixels (ry + d i, rx + d j) of one residue class form a dense
-// ceil(H / d) x ceil(W / d) image on which the conv is a plain 3x3.  A workgroup takes a tile of at most 16 x 16 outputs
+// ceil(H / d) x ceil(W / d) image on which the conv is a plain 3x3.  A workgroup takes a tile of at most 15 x 15 outputs
 // of one residue class and one 128-byte channel slab (8 x 16-byte chunks), stages the (th + 2) x (tw + 2) halo in LDS
 // -- every pixel of it one full 128-byte line -- and each thread forms 8 horizontally adjacent outputs of one chunk
 // from 3 x 10 LDS reads: 1.27 global requests per input element instead of the comb kernel's 4.5 (which all went
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_lattice_kernel(const T* __restr
                                                                 int act, int ny, int nx, int th, int tw) {
     constexpr int EPC = TT<T>::EPC;
     constexpr int CHS = 8 * EPC;                       // channels per slab (128 bytes)
-    __shared__ __attribute__((aligned(16))) uint4 halo[18 * 18 * 8];
+    __shared__ __attribute__((aligned(16))) uint4 halo[17 * 17 * 8];   // tiles of at most 15 x 15: 37 KB, four workgroups per CU
     __shared__ __attribute__((aligned(16))) float wl[11 * CHS];   // 9 taps, scale, shift of the slab's channels
     const int tid = threadIdx.x;
     unsigned t = blockIdx.x;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_lattice_kernel(const T* __restr
     const int sy0 = ty * th, sx0 = tx * tw;            // first lattice row / column of the tile
     const int hw_ = tw + 2, items = (th + 2) * hw_ * 8;
     // ---- halo: all of a thread's pieces requested before the first is written ----
-    constexpr int MAXP = (18 * 18 * 8 + 255) / 256;    // 11
+    constexpr int MAXP = (17 * 17 * 8 + 255) / 256;    // 10
     uint4 hv[MAXP];
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
@@ -443,7 +443,7 @@ int madm_dwconv3x3(int dtype, const void* x, const float* w, const float* scale,
         const bool fits = C % chs == 0 && dilation > 1;
         const bool pays = total >= ((size_t)1 << 21) && shmax >= 8 && swmax >= 8;
         if (fits && (force == 4 || (force == 0 && pays))) {
-            const int ny = (shmax + 15) / 16, nx = (swmax + 15) / 16;
+            const int ny = (shmax + 14) / 15, nx = (swmax + 14) / 15;
             const int th = (shmax + ny - 1) / ny, tw = (swmax + nx - 1) / nx;
             const size_t blocks = (size_t)B * dilation * dilation * ny * nx * (C / chs);
             MADM_REQUIRE(blocks < 0x7fffffffull, "dwconv3x3: grid too large");

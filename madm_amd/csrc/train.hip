@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
 }
 
 // The same gradient on the dilation's lattice (spatial.hip, dwconv3x3_lattice_kernel): a workgroup owns one residue
-// class (ry, rx) of one image and one 128-byte channel slab and walks that class's tiles of at most 16 x 16 lattice
+// class (ry, rx) of one image and one 128-byte channel slab and walks that class's tiles of at most 15 x 15 lattice
 // pixels; per tile the x halo sits in LDS (1.27 global requests per element instead of 9), every thread multiplies its 8
 // dy chunks with the 3 x 10 halo chunks around them into 9 x EPC register sums that live across the tiles; one LDS +
 // global atomic round per workgroup (measurements at the launcher).
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_lattice_kernel(const T* _
                                                                       int ny, int nx, int th, int tw) {
     constexpr int EPC = TT<T>::EPC;
     constexpr int CHS = 8 * EPC;
-    __shared__ __attribute__((aligned(16))) uint4 halo[18 * 18 * 8];
+    __shared__ __attribute__((aligned(16))) uint4 halo[17 * 17 * 8];   // tiles of at most 15 x 15: 37 KB, four workgroups per CU
     __shared__ float red[9 * CHS];
     const int tid = threadIdx.x;
     unsigned t = blockIdx.x;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_lattice_kernel(const T* _
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int j = 0; j < EPC; ++j) acc[k][j] = 0.f;
-    constexpr int MAXP = (18 * 18 * 8 + 255) / 256;
+    constexpr int MAXP = (17 * 17 * 8 + 255) / 256;
     for (int tile = 0; tile < ny * nx; ++tile) {
         const int ty = tile / nx, tx = tile - ty * nx;
         const int sy0 = ty * th, sx0 = tx * tw;
@@ -518,7 +518,7 @@ int madm_dwconv3x3_wgrad(int dtype, const void* x, const void* dy, int lddy, flo
         const int chs = 8 * epc;
         const int shmax = (H + dilation - 1) / dilation, swmax = (W + dilation - 1) / dilation;
         const bool fits = C % chs == 0 && dilation > 1;
-        const int ny = (shmax + 15) / 16, nx = (swmax + 15) / 16;
+        const int ny = (shmax + 14) / 15, nx = (swmax + 14) / 15;
         // a workgroup walks the ny * nx tiles of its class one after the other (load, barrier, multiply): with few tiles
         // per class nothing covers the loads -- head tensor, 2 x 512 x 512 x 1024: 1 415 -> 709 us at dilation 6 (36
         // tiles), 1 355 -> 905 at 12 (9), 1 388 -> 1 461 at 18 (4)
