@@ -646,7 +646,6 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? (NS == 2 ? 2 : 1) : (NS
 // Block = 16 channel quads x 16 rows (one row per thread): a 16-row x 64-channel output tile.
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const IgemmP p) {
-    kernarg_touch<5>();
     __shared__ float red[16][64][2];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int n = (blockIdx.x * 16 + tx) * 4;
@@ -733,7 +732,6 @@ constexpr size_t PGN_MAX_LDS = 96 * 1024;
 // V = floats per unit (4 when the group's channel count allows 16-byte accesses, else 2).
 template <typename T, int V>
 __global__ __launch_bounds__(PGN_THREADS) void splitk_groupnorm_kernel(const IgemmP p, const PostGn pn) {
-    kernarg_touch<6>();
     extern __shared__ __attribute__((aligned(16))) float pgn_vals[];
     __shared__ double pgn_red[2][PGN_THREADS / 64];
     __shared__ float pgn_mr[2];

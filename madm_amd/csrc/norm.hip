@@ -62,7 +62,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, int act,
                                                        const T* __restrict__ res, int ldres, const T* __restrict__ xsrc2) {
-    kernarg_touch<3>();   // 17 arguments + the hidden ones: otherwise three dependent scalar-cache misses in a kernel that is pure latency
     constexpr int EPC = TT<T>::EPC;
     if (xsrc2 && blockIdx.z == 1) {      // both sources of a concatenated input in one launch: grid.z picks the source
         x = xsrc2; c_off = C1; C = Ctot - C1;
