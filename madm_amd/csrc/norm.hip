@@ -31,12 +31,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
             float s[EPC], ss[EPC];
 #pragma unroll
             for (int j = 0; j < EPC; ++j) { s[j] = 0.f; ss[j] = 0.f; }
-            for (int r = r0 + ty; r < r1; r += rowlanes) {
-                uint4 v = *reinterpret_cast<const uint4*>(xb + (size_t)r * C + q * EPC);
-                float f[EPC];
-                chunk_to_f32<T>(v, f);
+            // four rows per trip, their loads issued together (one load per trip left the kernel at 1.6 .. 2.7 TB/s:
+            // tools/exp/bench_norm_bw.py); the sums keep the row order
+            for (int r = r0 + ty; r < r1; r += 4 * rowlanes) {
+                uint4 v[4];
 #pragma unroll
-                for (int j = 0; j < EPC; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = r + u * rowlanes;
+                    v[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (rr < r1) v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)rr * C + q * EPC);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {   // (rows past r1 contribute exact zeros)
+                    float f[EPC];
+                    chunk_to_f32<T>(v[u], f);
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) { s[j] += f[j]; ss[j] += f[j] * f[j]; }
+                }
             }
 #pragma unroll
             for (int j = 0; j < EPC; ++j) {

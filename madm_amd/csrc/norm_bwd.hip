@@ -95,22 +95,41 @@ __global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const T* __restrict__ 
         const T* xb = x + (size_t)b * HW * C;
         const T* db = dy + (size_t)b * HW * lddy + c_off;
         for (int q = tx; q < CPR; q += cols) {
-            float s1[EPC], s2[EPC];
+            float s1[EPC], s2[EPC], cr[EPC], cm[EPC], cg[EPC], cb[EPC];   // the column's constants live in registers
 #pragma unroll
-            for (int j = 0; j < EPC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-            for (int row = r0 + ty; row < r1; row += rowlanes) {
-                const uint4 xv = *reinterpret_cast<const uint4*>(xb + (size_t)row * C + q * EPC);
-                const uint4 dv = *reinterpret_cast<const uint4*>(db + (size_t)row * lddy + q * EPC);
-                float xf[EPC], df[EPC];
-                chunk_to_f32<T>(xv, xf);
-                chunk_to_f32<T>(dv, df);
+            for (int j = 0; j < EPC; ++j) {
+                const int c = q * EPC + j;
+                s1[j] = 0.f; s2[j] = 0.f;
+                cr[j] = r[c]; cm[j] = mr[c]; cg[j] = gm[c]; cb[j] = bt[c];
+            }
+            // four rows per trip, all eight loads issued together (one row per trip: 1.9 .. 3.2 TB/s for the pair of
+            // backward kernels, tools/exp/bench_norm_bw.py); the sums keep the row order
+            for (int row = r0 + ty; row < r1; row += 4 * rowlanes) {
+                uint4 xv[4], dv[4];
 #pragma unroll
-                for (int j = 0; j < EPC; ++j) {
-                    const int c = q * EPC + j;
-                    const float xh = xf[j] * r[c] + mr[c];
-                    const float dz = act_grad_f(xh * gm[c] + bt[c], df[j], act);
-                    s1[j] += dz;
-                    s2[j] += dz * xh;
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = row + u * rowlanes;
+                    xv[u] = make_uint4(0u, 0u, 0u, 0u);
+                    dv[u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (rr < r1) {
+                        xv[u] = *reinterpret_cast<const uint4*>(xb + (size_t)rr * C + q * EPC);
+                        dv[u] = *reinterpret_cast<const uint4*>(db + (size_t)rr * lddy + q * EPC);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (row + u * rowlanes < r1) {
+                        float xf[EPC], df[EPC];
+                        chunk_to_f32<T>(xv[u], xf);
+                        chunk_to_f32<T>(dv[u], df);
+#pragma unroll
+                        for (int j = 0; j < EPC; ++j) {
+                            const float xh = xf[j] * cr[j] + cm[j];
+                            const float dz = act_grad_f(xh * cg[j] + cb[j], df[j], act);
+                            s1[j] += dz;
+                            s2[j] += dz * xh;
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -184,30 +203,62 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
     __syncthreads();
 
-    const unsigned CPR = (unsigned)C / EPC;
-    const unsigned total = (unsigned)HW * CPR;
+    // threads = (column chunk, row lane): a thread keeps ONE 16-byte column (its six constants per channel in registers)
+    // and walks rows; four rows per trip with all their loads issued before the first store -- with one row per trip every
+    // load waited behind the previous row's store (loads and stores share vmcnt on gfx950 and retire out of order with
+    // respect to each other: the compiler can only wait with vmcnt(0)) and the kernel ran at half the copy rate
+    const int CPR = C / EPC;
+    const int cols = CPR < 256 ? CPR : 256;
+    const int rowlanes = 256 / cols;
+    const int tx = threadIdx.x % cols, ty = threadIdx.x / cols;
+    if (ty >= rowlanes) return;
     const T* xb = x + (size_t)b * HW * C;
     const T* db = dy + (size_t)b * HW * lddy + c_off;
     T* ob = dx + (size_t)b * HW * C;
     const T* rb = dres ? dres + (size_t)b * HW * lddres + c_off : nullptr;
-    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const unsigned row = idx / CPR, q = idx - row * CPR;
-        const uint4 xv = *reinterpret_cast<const uint4*>(xb + (size_t)idx * EPC);
-        const uint4 dv = *reinterpret_cast<const uint4*>(db + (size_t)row * lddy + q * EPC);
-        float xf[EPC], df[EPC], o[EPC], rf[EPC];
-        chunk_to_f32<T>(xv, xf);
-        chunk_to_f32<T>(dv, df);
-#pragma unroll
-        for (int j = 0; j < EPC; ++j) rf[j] = 0.f;
-        if (rb) chunk_to_f32<T>(*reinterpret_cast<const uint4*>(rb + (size_t)row * lddres + q * EPC), rf);
+    const int rstride = (int)gridDim.x * rowlanes;
+    for (int q = tx; q < CPR; q += cols) {
+        float cr[EPC], cm[EPC], cg[EPC], cb[EPC], ca[EPC], ck[EPC];
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
             const int c = q * EPC + j;
-            const float xh = xf[j] * r[c] + mr[c];
-            const float dz = act_grad_f(xh * gm[c] + bt[c], df[j], act);
-            o[j] = r[c] * (gm[c] * dz - kA[c] - xh * kB[c]) + rf[j];
+            cr[j] = r[c]; cm[j] = mr[c]; cg[j] = gm[c]; cb[j] = bt[c]; ca[j] = kA[c]; ck[j] = kB[c];
         }
-        *reinterpret_cast<uint4*>(ob + (size_t)idx * EPC) = f32_to_chunk<T>(o);
+        for (int row = (int)blockIdx.x * rowlanes + ty; row < HW; row += 4 * rstride) {
+            uint4 xv[4], dv[4], rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = row + u * rstride;
+                xv[u] = make_uint4(0u, 0u, 0u, 0u);
+                dv[u] = make_uint4(0u, 0u, 0u, 0u);
+                rv[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (rr < HW) {
+                    xv[u] = *reinterpret_cast<const uint4*>(xb + (size_t)rr * C + q * EPC);
+                    dv[u] = *reinterpret_cast<const uint4*>(db + (size_t)rr * lddy + q * EPC);
+                    if (rb) rv[u] = *reinterpret_cast<const uint4*>(rb + (size_t)rr * lddres + q * EPC);
+                }
+            }
+            uint4 ov[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float xf[EPC], df[EPC], o[EPC], rf[EPC];
+                chunk_to_f32<T>(xv[u], xf);
+                chunk_to_f32<T>(dv[u], df);
+                chunk_to_f32<T>(rv[u], rf);   // (zeros without a skip-path gradient)
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    const float xh = xf[j] * cr[j] + cm[j];
+                    const float dz = act_grad_f(xh * cg[j] + cb[j], df[j], act);
+                    o[j] = cr[j] * (cg[j] * dz - ca[j] - xh * ck[j]) + rf[j];
+                }
+                ov[u] = f32_to_chunk<T>(o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = row + u * rstride;
+                if (rr < HW) *reinterpret_cast<uint4*>(ob + (size_t)rr * C + q * EPC) = ov[u];
+            }
+        }
     }
 }
 
@@ -401,8 +452,11 @@ int madm_groupnorm_bwd_apply(int dtype, const void* x, const void* dy, int lddy,
     MADM_REQUIRE(dx && (!dgamma == !dbeta), "groupnorm_bwd_apply: dx missing or only one of dgamma / dbeta given");
     const int epc = madm_epc(dtype);
     MADM_REQUIRE(!dres || lddres % epc == 0, "groupnorm_bwd_apply: lddres must be a multiple of %d elements", epc);
-    const long long total = (long long)HW * (C / epc);
-    int strips = (int)((total + 256 * 4 - 1) / (256 * 4));
+    // a block covers rowlanes rows per step (threads = column chunks x row lanes) and every thread takes four rows per
+    // trip: enough blocks that a thread has at most ~4 trips, at most ~4096 blocks per launch
+    const int cpr = C / epc;
+    const int rowlanes = cpr < 256 ? 256 / cpr : 1;
+    int strips = (HW + rowlanes * 16 - 1) / (rowlanes * 16);
     const int want = (4096 + B - 1) / B;
     if (strips > want) strips = want;
     if (strips < 1) strips = 1;
