@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void image_to_im2col_kernel(const float* __res
 // because of the fused statistics: one f64 atomic per (block, channel, moment) lands on 512 addresses, and 2 048 atomics
 // on one address (one row per block) took as long as the two kernels this one replaces (122 us; they execute at the
 // memory side at ~50-85 ns each).  Measured in a graph loop, 2 x 512 x 512: 93.5 / 88.7 us with 2 / 4 rows per block.
-constexpr int STEM_SEG = 128, STEM_N = 128, STEM_ROWS = 4;
+constexpr int STEM_SEG = 128, STEM_N = 128, STEM_ROWS = 4, STEM_MFMA_ROWS = 8;
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restrict__ img, const float* __restrict__ wT,
                                                            const float* __restrict__ bias, T* __restrict__ out, int ldo,
@@ -215,6 +215,148 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
         float t = 0.f;                             // tid = channel * 2 + {sum, sum of squares}
 #pragma unroll
         for (int g = 0; g < 8; ++g) t += red[g * STEM_N * 2 + tid];
+        atomicAdd(stats + (size_t)b * STEM_N * 2 + tid, (double)t);
+    }
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane (igemm_common.hpp row16_sum)
+__device__ __forceinline__ float row16_sum_f(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));
+    return x;
+}
+
+// The same stem on the matrix pipe for the 16-bit types: the reference runs conv_in under fp16 autocast (image and weights
+// rounded to fp16, fp32 accumulation -- exactly an MFMA with K = 27 padded to 32), so nothing is lost against the exact-f32
+// FMAs above, which were VALU-bound (216 FMAs per pixel pair and lane: 78 us for 134 MB of output).  Block = 4 rows x 128
+// pixels, one row per wave = 8 tiles of 16 pixels; per tile the lane (pixel lane & 15, k group lane >> 4) gathers its 8
+// im2col values (k = (r * 3 + s) * 3 + c) from the normalised 16-bit window in LDS, 8 MFMAs give its pixel 8 x 4 channels,
+// which go through a wave-private padded LDS tile into full 256-byte lines.  Output statistics as above (f32 values
+// before rounding, f32 block partials, f64 atomics).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv3x3_mfma_kernel(const float* __restrict__ img, const float* __restrict__ wT,
+                                                                const float* __restrict__ bias, T* __restrict__ out, int ldo,
+                                                                int B, int H, int W, float mean, float inv_std,
+                                                                double* __restrict__ stats) {
+    static_assert(sizeof(T) == 2, "stem_conv3x3_mfma_kernel: 16-bit types");
+    constexpr int MROWS = STEM_MFMA_ROWS;                         // rows per block: two per wave
+    constexpr int TW = STEM_SEG + 2, TR = MROWS + 2;
+    constexpr int ROWB = STEM_N * 2 + 16;                        // padded row of the output staging tile
+    __shared__ __attribute__((aligned(16))) T tile[3 * TR * TW + 8];   // [c][input row][x], normalised, zero outside; + zeros for k >= 27
+    __shared__ __attribute__((aligned(16))) char stage[4 * 16 * ROWB]; // per wave: 16 pixels x 128 channels
+    __shared__ float red[4 * STEM_N * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const unsigned segs = (unsigned)(W + STEM_SEG - 1) / STEM_SEG;
+    const unsigned bands = (unsigned)(H + MROWS - 1) / MROWS;
+    const unsigned seg = blockIdx.x % segs, bb = blockIdx.x / segs;
+    const int b = (int)(bb / bands), y0 = (int)(bb - (unsigned)b * bands) * MROWS, x0 = (int)seg * STEM_SEG;
+    const size_t HW = (size_t)H * W;
+    const float* ib = img + (size_t)b * 3 * HW;
+    // window: row-major walk without divisions (18 rows of 130: thread t takes columns t, t + 256 of a row pair ...)
+    for (int cr = wave; cr < 3 * TR; cr += 4) {
+        const int c = cr / TR, r = cr - TR * c;
+        const int yy = y0 + r - 1;
+        for (int xx = lane; xx < TW; xx += 64) {
+            const int gx = x0 + xx - 1;
+            float t = 0.f;
+            if ((unsigned)yy < (unsigned)H && (unsigned)gx < (unsigned)W)
+                t = (ib[(size_t)c * HW + (size_t)yy * W + gx] - mean) * inv_std;
+            TT<T>::st(&tile[cr * TW + xx], t);
+        }
+    }
+    if (tid < 8) TT<T>::st(&tile[3 * TR * TW + tid], 0.f);
+    // weight fragments: lane = (channel frow of the 16-channel tile, k group fg): w[k = 8 fg + j][n = 16 t + frow]; the
+    // 27 x 128 f32 table comes in by coalesced float4 loads through the (not yet used) staging tile
+    {
+        float* wl = reinterpret_cast<float*>(stage);
+        for (int i = tid; i < 27 * STEM_N / 4; i += 256)
+            *reinterpret_cast<float4*>(wl + 4 * i) = *reinterpret_cast<const float4*>(wT + 4 * i);
+    }
+    __syncthreads();
+    uint4 wf[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float* wl = reinterpret_cast<const float*>(stage);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = fg * 8 + j;
+            f[j] = k < 27 ? wl[k * STEM_N + t * 16 + frow] : 0.f;
+        }
+        wf[t] = f32_to_chunk<T>(f);
+    }
+    f32x4 bv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float4 q = *reinterpret_cast<const float4*>(bias + t * 16 + fg * 4);
+        bv[t] = f32x4{q.x, q.y, q.z, q.w};
+    }
+    // the lane's 8 gather offsets (elements, relative to the window element of its pixel): k -> (tap r, s; channel c)
+    int goff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = fg * 8 + j;
+        const int tap = k / 3, c = k - 3 * tap, r = tap / 3, sx = tap - 3 * r;
+        goff[j] = k < 27 ? (c * TR + r) * TW + sx : -1;
+    }
+    __syncthreads();
+    f32x4 cs[8], cq[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { cs[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    char* st = stage + wave * 16 * ROWB;
+    const unsigned short* tw16 = reinterpret_cast<const unsigned short*>(tile);
+    const int nxt = (W - x0 + 15) / 16 < STEM_SEG / 16 ? (W - x0 + 15) / 16 : STEM_SEG / 16;   // wave-uniform
+#pragma unroll 1
+    for (int ry = wave; ry < MROWS; ry += 4) {
+        const int y = y0 + ry;
+        if (y >= H) break;
+#pragma unroll 1
+        for (int xt = 0; xt < nxt; ++xt) {
+            const int px = xt * 16 + frow;                 // pixel of this lane inside the segment
+            // A fragment: 8 window elements of pixel px (window row ry + r, column px + s)
+            const int pbase = ry * TW + px;
+            unsigned e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = tw16[goff[j] >= 0 ? pbase + goff[j] : 3 * TR * TW];
+            const uint4 af = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+            const bool inside = x0 + px < W;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                f32x4 acc = bv[t];
+                mma16<T>(wf[t], af, acc);                 // lane: pixel frow, channels 16 t + 4 fg .. + 3
+                if (inside) { cs[t] += acc; cq[t] += acc * acc; }
+                store4<T>(reinterpret_cast<T*>(st + frow * ROWB) + t * 16 + fg * 4, acc);
+            }
+            // the wave's 16 x 256-byte tile -> four instructions of 4 pixel rows x 16 lanes x 16 bytes (full lines)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int p = it * 4 + (lane >> 4), ch = lane & 15;
+                const uint4 v = *reinterpret_cast<const uint4*>(st + p * ROWB + ch * 16);
+                if (x0 + xt * 16 + p < W)
+                    *reinterpret_cast<uint4*>(out + (((size_t)b * H + y) * W + x0 + xt * 16 + p) * ldo + ch * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = row16_sum_f(cs[t][r]), q = row16_sum_f(cq[t][r]);
+                if (frow == 0) {
+                    red[(wave * STEM_N + t * 16 + fg * 4 + r) * 2] = a;
+                    red[(wave * STEM_N + t * 16 + fg * 4 + r) * 2 + 1] = q;
+                }
+            }
+        __syncthreads();
+        float t = 0.f;                                     // tid = channel * 2 + {sum, sum of squares}
+#pragma unroll
+        for (int g = 0; g < 4; ++g) t += red[g * STEM_N * 2 + tid];
         atomicAdd(stats + (size_t)b * STEM_N * 2 + tid, (double)t);
     }
 }
@@ -388,8 +530,19 @@ int madm_stem_conv3x3(int dtype, const float* img, const float* wT, const float*
     MADM_REQUIRE(nblocks < 0x7fffffffull, "stem_conv3x3: grid too large");
     hipStream_t s = (hipStream_t)stream;
     const unsigned blocks = (unsigned)nblocks;
-    MADM_DISPATCH_DTYPE(dtype, (stem_conv3x3_kernel<T><<<blocks, 256, 0, s>>>(img, wT, bias, (T*)out, ldo, B, H, W, mean,
-                                                                            1.0f / std, stats)));
+    // 16-bit modes: the MFMA kernel (MADM_STEM_KERNEL=1 keeps the exact-f32 FMA kernel for A/B runs); f32: the FMA kernel
+    const char* fe = getenv("MADM_STEM_KERNEL");
+    const bool fma = dtype == MADM_F32 || (fe && atoi(fe) == 1) || ldo % 8 != 0;
+    if (fma) {
+        MADM_DISPATCH_DTYPE(dtype, (stem_conv3x3_kernel<T><<<blocks, 256, 0, s>>>(img, wT, bias, (T*)out, ldo, B, H, W, mean,
+                                                                                1.0f / std, stats)));
+    } else {
+        const unsigned mblocks = (unsigned)((size_t)B * ((H + STEM_MFMA_ROWS - 1) / STEM_MFMA_ROWS) * ((W + STEM_SEG - 1) / STEM_SEG));
+        if (dtype == MADM_BF16)
+            stem_conv3x3_mfma_kernel<bf16_t><<<mblocks, 256, 0, s>>>(img, wT, bias, (bf16_t*)out, ldo, B, H, W, mean, 1.0f / std, stats);
+        else
+            stem_conv3x3_mfma_kernel<f16_t><<<mblocks, 256, 0, s>>>(img, wT, bias, (f16_t*)out, ldo, B, H, W, mean, 1.0f / std, stats);
+    }
     if (int rc = madm_check_launch("stem_conv3x3_kernel")) return rc;
     return launch_range_probe(img, (size_t)B * 3 * H * W, mean, 1.0f / std, minmax, s);
 }

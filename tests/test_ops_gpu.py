@@ -223,10 +223,26 @@ def test_stem_conv3x3(cuda, dtype, shape):
     mm = torch.tensor([float("inf"), float("-inf")], device="cuda")
     out = ops.stem_conv3x3(img.cuda(), wT, bias.cuda(), dtype, mean, std, stats=st, minmax=mm)
     torch.cuda.synchronize()
+    if dtype != torch.float32:
+        # 16-bit modes run the stem on the matrix pipe: the normalised image and the weights are rounded to the dtype and
+        # accumulated in f32 -- what conv_in does under the reference's autocast -- so THAT is the exact statement;
+        # against the unrounded conv only the operand rounding shows
+        e0 = rel_err(from_tokens(out, B, H, W), ref)[0]
+        assert e0 < {torch.bfloat16: 2e-2, torch.float16: 3e-3}[dtype], f"{e0:.3e}"
+        ref = F.conv2d(_q((img - mean) / std, dtype), _q(w, dtype), bias, padding=1)
     e, l2 = rel_err(from_tokens(out, B, H, W), ref)
     assert e < {torch.float32: 2e-6, torch.bfloat16: 6e-3, torch.float16: 8e-4}[dtype], f"{e:.3e} {l2:.3e}"
     sums = st.float().cpu()
     assert rel_err(sums[..., 0], ref.sum((2, 3)))[0] < 1e-4 and rel_err(sums[..., 1], (ref ** 2).sum((2, 3)))[0] < 1e-4
+    if dtype != torch.float32:   # the exact-f32 FMA kernel stays selectable (A/B runs) and keeps its tighter statement
+        import os
+        os.environ["MADM_STEM_KERNEL"] = "1"
+        try:
+            out1 = ops.stem_conv3x3(img.cuda(), wT, bias.cuda(), dtype, mean, std)
+        finally:
+            del os.environ["MADM_STEM_KERNEL"]
+        ref0 = F.conv2d((img - mean) / std, w, bias, padding=1)
+        assert rel_err(from_tokens(out1, B, H, W), ref0)[0] < {torch.bfloat16: 6e-3, torch.float16: 8e-4}[dtype]
     lo, hi = mm.tolist()
     x = (img - mean) / std
     assert abs(lo - float(x.min())) < 1e-6 and abs(hi - float(x.max())) < 1e-6
