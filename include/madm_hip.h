@@ -271,8 +271,9 @@ int madm_image_to_im2col3x3(int dtype, const float* img, void* out, int B, int H
                             float mean, float std, float* minmax, void* stream);
 
 /* The stem itself, without the detour: out[pixel][n] (dtype, row stride ldo) = bias[n] + sum_k wT[k][n] * x_k, x_k the
- * normalised image value of tap k = (kh*3 + kw)*3 + c (zero outside the image), N = 128 (the SD VAE's conv_in), exact f32
- * FMAs; wT f32 [27][N]; stats (NULL or f64 [B][N][2], zeroed by the caller) += per-(image, channel) sum / sum of squares
+ * normalised image value of tap k = (kh*3 + kw)*3 + c (zero outside the image), N = 128 (the SD VAE's conv_in).  MADM_F32:
+ * exact f32 FMAs; MADM_BF16 / MADM_F16 (ldo a multiple of 8): x_k and wT rounded to the dtype, f32 accumulation on the
+ * matrix pipe (K = 27 padded to 32) -- what conv_in computes under the reference's autocast; wT f32 [27][N]; stats (NULL or f64 [B][N][2], zeroed by the caller) += per-(image, channel) sum / sum of squares
  * of the output (the statistics of the GroupNorm that follows, as the conv epilogues produce them); minmax as above.
  * Replaces vae.encoder.conv_in of vae_encoder (ldm_diffusers.py:287) together with the normalisation of :145-147. */
 int madm_stem_conv3x3(int dtype, const float* img, const float* wT, const float* bias, void* out, int ldo, int B, int H,

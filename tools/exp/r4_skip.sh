@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
 for s in none layernorm gn_apply attention "re:attn d40 Lq4096 Lk4096" "re:^k3 s1 M(524288|131072|32768) " "re:^k3 s2" "re:^k3 s1 M8192 N512" \
          "re:^k3 s1( up)? M(8192 N(320|640)|2048|512|128) " "re:^k1 s1 M(8192|2048|512|128) N(320|640|1280) K(320|640|1280)$" \
-         "re:^k1 s1 M(8192 N2560|2048 N5120|512 N10240)" "re:^k1 s1 M(8192 N320 K1280|2048 N640 K2560|512 N1280 K5120)" \
+         "re:^k1 s1 M(8192 N2560|2048 N5120|512 N10240)" "re:^k1 s1 M(8192 N320 K1600|2048 N640 K3200|512 N1280 K6400)" \
          "re:^k1 s1 M(8192 N960|2048 N1920|512 N3840)" "re:^k1 s1 M(131072|32768|4096)"; do
   if [ "$s" = none ]; then v=""; else v=$s; fi
   MADM_EXP_SKIP="$v" python bench.py --no-cpu-baseline --no-kernel-profile --no-alt-dtype --steps 40 --warmup 8 2>/dev/null \
