@@ -17,8 +17,16 @@ template <int N> __device__ __forceinline__ void c3_wait_vmcnt() { asm volatile(
 template <int N> __device__ __forceinline__ void c3_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 #endif
 
+#ifdef C3D_STAMPS   // tools/exp/stamps_c3d.py: block timeline (block 5 / thread 0) + per-tap stamps of the first chunks
+__device__ unsigned long long g_c3d_stamps[256];
+#define C3D_STAMP(k_) if (blockIdx.x == 5 && blockIdx.z == 0 && threadIdx.x == 0 && (k_) < 256) g_c3d_stamps[(k_)] = __builtin_readcyclecounter();
+#else
+#define C3D_STAMP(k_)
+#endif
+
 template <typename T, int BN, bool FUSE>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
+    C3D_STAMP(0);
     kernarg_touch<5>();
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS address-space casts and gfx asm: device pass only (the host needs the stub)
     constexpr int EPC = TT<T>::EPC;
@@ -161,14 +169,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    C3D_STAMP(1);
     if (S > 0) {
         D3_LOAD_HALO(ck0);
         D3_DMA_W();              // the first two weight tiles fly while the group statistics are folded and the
         if (S > 1) D3_DMA_W();   // first halo chunk is normalised (the fold's plain LDS stores make the compiler drain
         if (FUSE) gn_fold_groups(p, b, gstat);   // them: everything requested so far lands together)
         __syncthreads();
+        C3D_STAMP(2);
         D3_STORE_HALO(ck0);
     }
+    C3D_STAMP(3);
 
     // fragment addressing, all of it hoisted out of the tap loop (the nine taps are unrolled: tap, ring slot and the halo
     // row / column shift are compile-time, a fragment address is a precomputed register -- or that register ^ 64 for the
@@ -192,9 +203,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p
             const int cur = tap % 3;   // 9 taps per chunk: the ring slot of a tap is the same in every chunk
             // weight tile s has landed once at most the next tile's LW loads of this wave are outstanding (the halo loads
             // of tap 0 are issued BEFORE that tile's DMA, so they are older and covered by the same wait)
+            C3D_STAMP(16 + ((ck - ck0) * 9 + tap) * 3);
             if (tap < 8 || next_chunk) c3_wait_vmcnt<LW>();
             else c3_wait_vmcnt<0>();
+            C3D_STAMP(16 + ((ck - ck0) * 9 + tap) * 3 + 1);
             __builtin_amdgcn_s_barrier();   // this tap's tile (and at tap 0 the new halo) visible; ring slot (tap + 2) % 3 is free
+            C3D_STAMP(16 + ((ck - ck0) * 9 + tap) * 3 + 2);
             if (tap == 0 && next_chunk) D3_LOAD_HALO(ck + 1);
             if (tap < 7 || next_chunk) D3_DMA_W();
             __builtin_amdgcn_sched_barrier(0);
@@ -238,9 +252,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p
 #undef D3_LOAD_HALO
 #undef D3_STORE_HALO
 #undef D3_DMA_W
+    C3D_STAMP(4);
     c3_wait_vmcnt<0>();
     __syncthreads();   // the LDS becomes the statistics scratch of the epilogue
     halo_tile_epilogue<T, BN>(p, acc, b, py0, px0, n0, z, reinterpret_cast<float*>(smem_raw));
+    C3D_STAMP(5);
+#ifdef C3D_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    C3D_STAMP(6);
+#endif
 #endif
 }
 
@@ -266,6 +286,11 @@ int launch_conv3x3_halo_dma(const IgemmP& p, int bn, hipStream_t s) {
     if (bn == 128) return fuse ? launch_dma_one<T, 128, true>(p, s) : launch_dma_one<T, 128, false>(p, s);
     return fuse ? launch_dma_one<T, 64, true>(p, s) : launch_dma_one<T, 64, false>(p, s);
 }
+#ifdef C3D_STAMPS
+extern "C" int madm_debug_read_c3d_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c3d_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 template int launch_conv3x3_halo_dma<float>(const IgemmP&, int, hipStream_t);
 template int launch_conv3x3_halo_dma<bf16_t>(const IgemmP&, int, hipStream_t);
 template int launch_conv3x3_halo_dma<f16_t>(const IgemmP&, int, hipStream_t);
