@@ -558,6 +558,23 @@ extern "C" int madm_conv2d_wgrad(const madm_conv2d_wgrad_args* a, void* stream) 
         const int cap = total_steps / 2;
         if (splitm > cap) splitm = cap;
         if (splitm < 1) splitm = 1;
+        if (total_steps <= 512) {
+            // Short reductions (the UNet's 8^2 .. 64^2 maps): a step costs ~1 us whatever the tile (one operand round trip:
+            // the loop prefetches one step ahead), a slice's partial tile 16 384 float atomics at ~2.9 ps each, a sole
+            // owner's read-modify-write ~4.2 ps per element.  Model  rounds(s) * steps / s * 1 us + atomics(s)  fitted to
+            // tools/exp/sweep_wgrad_splitm.py (M 2048 x 640 x 640: 37.5 us at the rule above (25 slices) -> 22.2 at 8;
+            // M 512 x 1280 x 1280: 37.7 -> 21.6 at 2; M 512 x 1280 x 5120: 63.8 -> 42.7 at 1)
+            double best = 1e30;
+            int bs = 1;
+            for (int sm = 1; sm <= 32 && sm <= total_steps; ++sm) {
+                const int per = (total_steps + sm - 1) / sm;
+                const int blocks = tiles * ((total_steps + per - 1) / per);
+                const int rounds = (blocks + 511) / 512;
+                const double t = (double)rounds * per * 1.0 + (double)tiles * 16384.0 * (sm > 1 ? sm * 2.9e-6 : 4.2e-6);
+                if (t < best) { best = t; bs = sm; }
+            }
+            splitm = bs;
+        }
     }
     if (splitm > total_steps) splitm = total_steps;
     MADM_REQUIRE(splitm <= 65535 && tilesK <= 65535, "conv2d_wgrad: grid too large");
