@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
     const int total_steps = (p.M + PX - 1) / PX;
     const int nsteps = min(p.steps_per_slice, total_steps - step0);
     if (nsteps <= 0) return;
+    const int mend = (step0 + nsteps) * PX < p.M ? (step0 + nsteps) * PX : p.M;   // first pixel beyond this slice
 
     const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dout, 0, p.bytesd, 0x00020000);
     // this thread's weight column: tap and channel are fixed, only the pixel moves
@@ -78,26 +79,33 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
     }
     const int IHe = p.upsample ? 2 * p.IH : p.IH, IWe = p.upsample ? 2 * p.IW : p.IW;
 
-    u32x4 rd[LI], ra[LI];
-    auto load_step = [&]() {
+    // Two register sets: the operands of step s + 2 are requested before step s is multiplied and written to LDS after
+    // step s + 1 -- two MFMA phases of lead instead of none (one set: every step waited a full operand round trip, ~1 us
+    // for 256 clocks of MFMA work: tools/exp/sweep_wgrad_splitm.py, one slice).  No condition around a request (steps past
+    // the slice read out-of-range offsets = zeros, and are multiplied as zeros): the compiler keeps counted waits only in
+    // straight-line code; three rotating sets under conditions made it drain every step.
+    u32x4 rdA[LI], raA[LI], rdB[LI], raB[LI];
+    auto load_step = [&](u32x4 (&rd)[LI], u32x4 (&ra)[LI]) {
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
-            const bool m_ok = pm[i] < p.M;
-            const unsigned offd = (unsigned)(pm[i] * p.ldd + n0 + cc * EPC) * (unsigned)sizeof(T);
-            rd[i] = __builtin_amdgcn_raw_buffer_load_b128(rsd, (m_ok && n_ok) ? offd : OOB, 0, 0);
-            unsigned offa = OOB;
-            if (m_ok && kc_ok) {
-                if (p.lin) {
-                    offa = (unsigned)(pm[i] * lda + ca) * (unsigned)sizeof(T);
-                } else {
-                    int iy = py[i] * p.stride - p.pad_t + tr, ix = px[i] * p.stride - p.pad_l + ts;
-                    if ((unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe) {
-                        if (p.upsample) { iy >>= 1; ix >>= 1; }
-                        offa = (unsigned)(((pb[i] * p.IH + iy) * p.IW + ix) * lda + ca) * (unsigned)sizeof(T);
-                    }
-                }
+            // branch-free per lane: an invalid row / column / tap position sets bit 31 of the offset (out of range for the
+            // descriptor: zeros).  Written as "cond ? off : OOB" the compiler built two loads behind exec masks and had to
+            // drain vmcnt between them (the address temporary shared the destination's registers).
+            const bool m_ok = pm[i] < mend;   // (steps past the slice must not read the next slice's pixels)
+            const unsigned badd = (unsigned)(!(m_ok && n_ok)) << 31;
+            const unsigned offd = ((unsigned)(pm[i] * p.ldd + n0 + cc * EPC) * (unsigned)sizeof(T)) | badd;
+            rd[i] = __builtin_amdgcn_raw_buffer_load_b128(rsd, offd, 0, 0);
+            unsigned offa;
+            bool a_ok = m_ok && kc_ok;
+            if (p.lin) {   // uniform
+                offa = (unsigned)(pm[i] * lda + ca) * (unsigned)sizeof(T);
+            } else {
+                int iy = py[i] * p.stride - p.pad_t + tr, ix = px[i] * p.stride - p.pad_l + ts;
+                a_ok = a_ok && (unsigned)iy < (unsigned)IHe && (unsigned)ix < (unsigned)IWe;
+                if (p.upsample) { iy >>= 1; ix >>= 1; }   // uniform
+                offa = (unsigned)(((pb[i] * p.IH + iy) * p.IW + ix) * lda + ca) * (unsigned)sizeof(T);
             }
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, offa, 0, 0);
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsa, offa | ((unsigned)(!a_ok) << 31), 0, 0);
             pm[i] += PX;
             if (!p.lin) {   // (a linear layer is OW = 1: the walk below would take PX iterations per step for nothing)
                 px[i] += PX;
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
     float bsum[EPC];
 #pragma unroll
     for (int j = 0; j < EPC; ++j) bsum[j] = 0.f;
-    auto store_step = [&](int stage) {
+    auto store_step = [&](int stage, const u32x4 (&rd)[LI], const u32x4 (&ra)[LI]) {
         char* d = smem + stage * 2 * TILEB;
 #pragma unroll
         for (int i = 0; i < LI; ++i) {
@@ -136,13 +144,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_step();
-    store_step(0);
+    load_step(rdA, raA);   // step 0
+    load_step(rdB, raB);   // step 1
+    store_step(0, rdA, raA);
     __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const bool more = s + 1 < nsteps;
-        if (more) load_step();
-        const char* td = smem + (s & 1) * 2 * TILEB;
+    auto compute_step = [&](int stage) {
+        const char* td = smem + stage * 2 * TILEB;
         const char* ta = td + TILEB;
         uint4 fd[4], fa[4];
         if constexpr (sizeof(T) == 2) {
@@ -193,7 +200,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const WgradP p) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) mma16<T>(fd[j], fa[i], acc[j][i]);
-        if (more) store_step((s + 1) & 1);
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        load_step(rdA, raA);            // step s + 2
+        compute_step(0);                // step s
+        store_step(1, rdB, raB);        // step s + 1
+        __syncthreads();
+        load_step(rdB, raB);            // step s + 3
+        compute_step(1);                // step s + 1 (zeros past the slice)
+        store_step(0, rdA, raA);        // step s + 2
         __syncthreads();
     }
 
