@@ -129,7 +129,9 @@ def main():
     ap.add_argument("--max-m", type=int, default=8192, help="largest M tuned (the VAE's 512^2 .. 128^2 maps lie above)")
     ap.add_argument("--rows", default="", help="write MADM_TUNED_FILE rows of the side-by-side winners here")
     ap.add_argument("--only", default="", help="regex on the shape description")
-    ap.add_argument("--workload", default="extract", choices=["extract", "eval"])
+    ap.add_argument("--workload", default="extract", choices=["extract", "eval", "train"],
+                    help="train: the launches of one optimisation step (forward + data gradients; eager, one stream: use --streams 1); "
+                         "rows are written only for shapes the table does not hold yet")
     args = ap.parse_args()
     torch.set_grad_enabled(False)
     from madm_amd.ldm_rocm import LdmRocm
@@ -141,6 +143,14 @@ def main():
         args.batch = 1
         m = bench.build_eval_model(dtype, torch.device("cuda"))
         call = ([{"target_second_modality": 255.0 * torch.rand((3, 512, 512)).cuda()}],)
+    elif args.workload == "train":   # BASELINE configs[3]: one MadmTrainer step (its conv2d launches incl. the data gradients)
+        from madm_amd.train import MadmTrainer
+        torch.set_grad_enabled(True)
+        model = bench.build_train_model(dtype, torch.device("cuda"), False)
+        trainer = MadmTrainer(model, lr=5e-6, weight_decay=0.05, grad_clip=0.01, dist=None, amp=True)
+        data = bench.train_inputs(args.batch, 512, torch.device("cuda"))
+        m = lambda d: trainer.run_step(d)
+        call = (data,)
     else:
         m = LdmRocm("", [], [5, 8, 11], [], input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
                     compute_dtype=dtype, weights='synthetic', seed=0)
@@ -152,15 +162,24 @@ def main():
     torch.cuda.synchronize()
     rec, ops.PROFILE = ops.PROFILE, None
     del m
+    if args.workload == "train":
+        del trainer, model
+        torch.set_grad_enabled(False)
     torch.cuda.empty_cache()
     classes = collections.OrderedDict()
     for name, _, e0, e1, desc, _, _ in rec:
-        if name.startswith(("attn", "stem_")):
+        if name.startswith(("attn", "stem_", "conv2d_wgrad")):
             continue
         key = re.sub(r" sk\d+( \+gn)?$", "", desc)
         c = classes.setdefault(key, {"n": 0, "us": 0.0, "name": name, "desc": desc})
         c["n"] += 1
         c["us"] += e0.elapsed_time(e1) * 1e3
+    table_keys = set()
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "madm_amd", "csrc", "igemm_tuned.inc")
+    for line in open(inc):
+        mm = re.match(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", line)
+        if mm:
+            table_keys.add(tuple(int(mm.group(i)) for i in (2, 3, 4, 5, 6)))
     streams = [torch.cuda.Stream() for _ in range(args.streams)]
     rows, tot = [], collections.defaultdict(float)
     print(f"{'shape':44s} {'n':>3s} | {'current':>9s} {'alone':>7s} {'side':>7s} | {'best alone':>10s} {'us':>7s} | {'best side':>10s} {'alone':>7s} {'side':>7s}")
@@ -210,6 +229,8 @@ def main():
         print(f"{key:44s} {n:3d} | sk{d['sk']:<7d} {cur[0]:7.1f} {cur[1]:7.1f} | t{ba[0][0]}/sk{ba[0][1]:<6d} {ba[1][0]:7.1f} | "
               f"t{bs[0][0]}/sk{bs[0][1]:<6d} {bs[1][0]:7.1f} {bs[1][1]:7.1f}", flush=True)
         variant = 1 if d["gn"] else (2 if d["up"] else (3 if d["s"] == 2 else 0))
+        if args.workload == "train" and (d["M"], d["N"], d["K"], d["k"], variant) in table_keys:
+            continue   # (a shape of the extractor's table: tuned side by side, not to be replaced by a lone-launch choice)
         if bs[1][1] < 0.97 * cur[1]:
             rows.append(f"1 {d['M']} {d['N']} {d['K']} {d['k']} {variant} {bs[0][0]} {bs[0][1]}   # side {cur[1]:.1f} -> {bs[1][1]:.1f} us, alone {cur[0]:.1f} -> {bs[1][0]:.1f}")
         del layers
