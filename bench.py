@@ -91,6 +91,9 @@ def parse():
                     help="train workload, N > 1: gradient exchange per bucket (dist.GradBucketReducer): all_reduce, or "
                          "reduce_scatter + all_gather (one direct exchange per peer on the xGMI mesh)")
     ap.add_argument("--wire", default="f32", choices=["f32", "bf16", "f16"], help="train workload: gradient wire type")
+    ap.add_argument("--no-calib", action="store_true",
+                    help="skip the two calibration measurements (calib / value_normalised in the line): for rocprofv3 passes, "
+                         "whose kernel tables should hold the step's kernels only")
     ap.add_argument("--no-alt-dtype", action="store_true",
                     help="skip the second timed run of the extract workload in the other 16-bit type (alt_dtype in the line)")
     ap.add_argument("--dry-launch", action="store_true",
@@ -99,11 +102,19 @@ def parse():
     return ap.parse_args()
 
 
-def make_inputs(B, size, device):
-    img = torch.rand((B, 3, size, size), generator=torch.Generator().manual_seed(1234))
-    cond = 0.02 * torch.randn((1, 77, 768), generator=torch.Generator().manual_seed(1235))
+def make_inputs(B, size, device, seed=0):
+    img = torch.rand((B, 3, size, size), generator=torch.Generator().manual_seed(1234 + 7919 * seed))
+    cond = 0.02 * torch.randn((1, 77, 768), generator=torch.Generator().manual_seed(1235 + 7919 * seed))
     return {"img": img.to(device), "cond_inputs": cond.repeat_interleave(B, 0).to(device),
             "cond_emb": torch.zeros((B, 1, 1280), device=device)}
+
+
+POOL = 16   # distinct seeded batches resident in HBM; step i submits batch i mod POOL (a new batch on every step of the timed
+# region at the driver's K = 20 up to the pool size, then the pool repeats: 16 x 6.3 MB of images)
+
+
+def make_input_pool(B, size, device, n=POOL):
+    return [make_inputs(B, size, device, seed=i) for i in range(n)]
 
 
 def build_eval_model(dtype, device, finetune_unet='no', slide=False, num_classes=11):
@@ -216,7 +227,8 @@ def kernel_profile(model, inputs):
       (Round 4: attention too -- its 22 short launches at L <= 1024 read 18 .. 21 us each by single pairs against 8 .. 22 us by
       rocprofv3's timestamps of the same kernels, profiles/round4_final_last_replay.txt.)
 
-    Returns {kernel: (launches, raw_ms, algorithmic_flops, algorithmic_bytes, differenced_ms)}."""
+    Returns ({kernel: (launches, raw_ms, algorithmic_flops, algorithmic_bytes, differenced_ms)},
+             {kernel: {layer description "M.. N.. K.. ...": [launches, flops, bytes, differenced_ms]}})."""
     from madm_amd import ops
     for _ in range(2):
         model(*inputs)
@@ -234,13 +246,18 @@ def kernel_profile(model, inputs):
     raw = one_pass(False)
     dif = one_pass(True)
     assert [r[0] for r in raw] == [r[0] for r in dif]
-    agg = {}
-    for (name, flops, e0, e1, _, nbytes, _p), (_, _, d0, d1, _, _, dp) in zip(raw, dif):
+    agg, layers = {}, {}
+    for (name, flops, e0, e1, desc, nbytes, _p), (_, _, d0, d1, _, _, dp) in zip(raw, dif):
         n, ms, fl, by, dms = agg.get(name, (0, 0.0, 0.0, 0, 0.0))
         t_raw = e0.elapsed_time(e1)
         t_dif = max(d1.elapsed_time(dp.e2) - d0.elapsed_time(d1), 1e-4) if dp.e2 is not None else t_raw
         agg[name] = (n + 1, ms + t_raw, fl + flops, by + nbytes, dms + t_dif)
-    return agg
+        row = layers.setdefault(name, {}).setdefault(desc, [0, 0.0, 0, 0.0])
+        row[0] += 1
+        row[1] += flops
+        row[2] += nbytes
+        row[3] += t_dif
+    return agg, layers
 
 
 CALIB_REF = {"mfma_loop_tflops": 2000.0, "h16_128x128_512sq_us": 141.0}   # the middle of the boxes seen in round 4 with
@@ -371,9 +388,10 @@ def main():
         slide = args.workload == "slide"
         model = build_eval_model(dtype, device, slide=slide, num_classes=9 if slide else 11)
         ldm = model.backbone.feature_extractor.ldm_extractor
-        call = ([{"target_second_modality": 255.0 * torch.rand((3, args.size, args.size * (2 if slide else 1)),
-                                                                generator=torch.Generator().manual_seed(777)).to(device)}],)
-        return run(args, model, call, ldm, rank, world, device, dist, mdist)
+        pool = [[{"target_second_modality": 255.0 * torch.rand((3, args.size, args.size * (2 if slide else 1)),
+                                                                generator=torch.Generator().manual_seed(777 + i)).to(device)}]
+                for i in range(POOL // 2)]
+        return run(args, model, (pool[0],), ldm, rank, world, device, dist, mdist, pool)
     model = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=[],
                     input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
                     compute_dtype=dtype, weights='synthetic', seed=0, device=device)
@@ -384,27 +402,35 @@ def main():
                                "Depth")
         model.unet.set_adapter(["Depth"])
         weights.randomize_lora_B_(model.unet)
-    inputs = make_inputs(args.batch, args.size, device)
-    return run(args, model, (inputs, "rgb"), model, rank, world, device, dist, mdist)
+    pool = make_input_pool(args.batch, args.size, device)
+    return run(args, model, (pool[0], "rgb"), model, rank, world, device, dist, mdist, pool)
 
 
-def run(args, model, call, ldm, rank, world, device, dist, mdist):
+def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
+    """``pool``: the distinct input batches of the workload (already in HBM); step i submits pool[i mod len(pool)]."""
     torch.set_grad_enabled(False)   # inference workloads (with --lora the adapters are trainable: no tape wanted here)
-    # eager warm-up: packs weights, sizes workspaces, checks the input range once
+    # eager warm-up: packs weights, sizes workspaces; the reference's range assert (ldm_diffusers.py:147) runs as a host sync
+    # here and in every other EAGER call below -- the graph runners keep it as a deferred check (pipeline.DeferredRangeCheck)
     model(*call)
     torch.cuda.synchronize()
-    ldm.check_input_range = False
 
-    prof = None
+    calib = None
+    if rank == 0 and args.workload == "extract" and args.dtype in ("f16", "bf16") and not args.no_calib:
+        # before the warm-up and the timed region: a kernel trace of this process ends with the step's own launches
+        calib = calibrate(device, {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype])
+    prof = layers = None
     if rank == 0 and not args.no_kernel_profile:
-        prof = kernel_profile(model, call)
+        prof, layers = kernel_profile(model, call)
 
     first_stream = None      # set when the steps run on streams of their own
     staged = args.workload == "extract" and args.pipeline > 0 and not args.no_graph
+    graphed = args.workload in ("eval", "slide") and not args.no_graph
     graphs, outs, streams = [], [], [None]
+    runner = None
 
     def capture_whole_forward(nstreams, nexec):
-        """Whole-forward hipGraph executables, round-robin on ``nstreams`` streams."""
+        """Whole-forward hipGraph executables over ONE fixed batch, round-robin on ``nstreams`` streams (reference points and
+        profiling runs; the product runners are pipeline.StagedExtractor / GraphedInference)."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -444,8 +470,8 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
         return a.elapsed_time(b) / args.steps
 
     if args.no_graph:
-        def step():
-            return model(*call)
+        def step(i):
+            return model(*((pool[i % len(pool)],) + tuple(call[1:])))
     elif staged:
         # the pipeline's streams are the FIRST streams this process creates: four busy streams run side by side only when
         # they sit on four different hardware pipes, and the runtime hands queues out in creation order (measured:
@@ -453,51 +479,64 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
         # profiles/round2_unet_concurrency.txt); the whole-forward executable of the serial_* reference point is built
         # after the timed region
         from madm_amd.pipeline import StagedExtractor
-        pipe = StagedExtractor(ldm, call[0], unet_streams=args.pipeline)
+        # A/B switches for the cost of the product API's per-submit work: MADM_EXP_NO_SYNC_INPUTS=1
+        # drops the caller-stream event, MADM_EXP_NO_RANGE=1 the deferred range check
+        runner = pipe = StagedExtractor(ldm, pool[0], unet_streams=args.pipeline,
+                                        sync_inputs=not int(os.environ.get("MADM_EXP_NO_SYNC_INPUTS", "0")),
+                                        range_check=False if int(os.environ.get("MADM_EXP_NO_RANGE", "0")) else None)
 
-        def step():
-            return pipe.submit()[0]
+        def step(i):
+            return pipe.submit(pool[i % len(pool)])[0]
         first_stream = pipe.s_enc
+    elif graphed:
+        from madm_amd.pipeline import GraphedInference
+        runner = GraphedInference(model, pool[0], streams=max(1, args.streams), slots=max(1, args.graphs, args.streams))
+
+        def step(i):
+            return runner.submit(pool[i % len(pool)])[0]
+        first_stream = runner.streams_[0]
     else:
         graphs, outs, streams = capture_whole_forward(args.streams if args.streams > 1 else 0,
                                                       max(1, args.graphs, args.streams))
-        turn = [0]
 
-        def step():
-            i = turn[0] % len(graphs)
-            turn[0] += 1
-            st = streams[i % len(streams)]
+        def step(i):
+            j = i % len(graphs)
+            st = streams[j % len(streams)]
             if st is None:
-                graphs[i].replay()
+                graphs[j].replay()
             else:
                 with torch.cuda.stream(st):
-                    graphs[i].replay()
-            return outs[i]
+                    graphs[j].replay()
+            return outs[j]
 
         first_stream = streams[0]
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     torch.cuda.synchronize()
     serial_ms = None
-    if not args.no_graph and not staged and args.streams > 1:
+    if graphed and args.streams > 1:
+        serial_ms = serial_reference(runner.graphs[0], runner.streams_[0])
+    elif not args.no_graph and not staged and args.streams > 1:
         serial_ms = serial_reference(graphs[0], streams[0])
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     # The timed region starts from an idle device (synchronize above) and ends with a device synchronize; `value` is the
     # wall clock between them.  With several streams NOTHING else is enqueued in the region -- no fork from / join into a
-    # timing stream, no timing events: every variant of a device-side bracket measured this round cost throughput (staged
+    # timing stream, no timing events: every variant of a device-side bracket measured in round 2 cost throughput (staged
     # pipeline, same box: 303 images/s bare, 274 with an idle timing stream that joins at the end, 217 forked from and
     # joined into the legacy null stream as in round 1; a queue that sits on a wait keeps its hardware pipe busy and the
     # pipe's other queue -- one of the four working streams -- starves).  device_ms_per_step exists for one stream only.
+    # What a submit enqueues besides the two graph launches: an event record on the (idle) caller stream + the encoder
+    # stream's wait for it, three device-to-device input copies, one 8-byte device-to-pinned copy of the range probe.
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     single = first_stream is None
     t0 = time.perf_counter()
     if single:
         ev0.record()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     if single:
         ev1.record()
     torch.cuda.synchronize()
@@ -505,11 +544,13 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
     if dist is not None:
         dist.barrier()
         elapsed = mdist.max_over_ranks(elapsed, dist, device)
+    range_checked = None
+    if runner is not None:
+        runner.drain()                # the range checks still pending (the device is idle: nothing to wait for)
+        if runner.range_check is not None:
+            range_checked = runner.range_check.checked
     alt = None
     conc = None
-    calib = None
-    if rank == 0 and args.workload == "extract" and args.dtype in ("f16", "bf16"):
-        calib = calibrate(device, {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype])
     if staged:
         conc = pipe.concurrency_probe()
         if world == 1 and args.dtype in ("f16", "bf16") and not args.no_alt_dtype and not args.lora:
@@ -523,19 +564,20 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
                          device=device)
             m2(*call)
             torch.cuda.synchronize()
-            m2.check_input_range = False
-            pipe2 = StagedExtractor(m2, call[0], unet_streams=args.pipeline, streams=pipe.streams)
-            for _ in range(args.warmup):
-                pipe2.submit()
+            pipe2 = StagedExtractor(m2, pool[0], unet_streams=args.pipeline, streams=pipe.streams)
+            for i in range(args.warmup):
+                pipe2.submit(pool[i % len(pool)])
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
-                pipe2.submit()
+            for i in range(args.steps):
+                pipe2.submit(pool[(args.warmup + i) % len(pool)])
             torch.cuda.synchronize()
             el2 = time.perf_counter() - t1
+            pipe2.drain()
             alt = {other: {"value": round(args.batch * args.steps / el2, 3), "unit": "images/s",
                            "ms_per_step": round(1e3 * el2 / args.steps, 4),
-                           "note": "same process, same staged pipeline, streams and step counts, run after the headline region"}}
+                           "note": "same process, same staged pipeline, streams, inputs and step counts, run after the headline "
+                                   "region"}}
             del pipe2, m2
         gs_, _, sts_ = capture_whole_forward(1, 1)
         serial_ms = serial_reference(gs_[0], sts_[0])
@@ -548,6 +590,31 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
         # projections) + the head on the 512 x 1024 canvas (2 x 1 821.27)
         alg = {"extract": ALG_FLOP_PER_IMAGE, "eval": 6.34725e12,
                "slide": 3 * (1.91993e12 + 2.51452e12 + 0.09153e12) + 2 * 1.82127e12}[args.workload]
+        fed = (f"every step submits a different seeded batch (pool of {len(pool)}, resident in HBM) through "
+               "{}.submit(batched_inputs): the inputs are copied into the slot's static buffers on the device per step")
+        if args.no_graph:
+            launch = "eager launches, a different seeded batch per step"
+        elif staged:
+            launch = (f"staged hipGraph pipeline (madm_amd/pipeline.py): VAE-encoder graphs on 1 stream, UNet graphs on "
+                      f"{args.pipeline} streams, up to {args.pipeline + 1} batches ({(args.pipeline + 1) * args.batch} images) in "
+                      f"flight, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}; "
+                      + fed.format("StagedExtractor") + "; serial_* = whole-forward graph, one batch in flight")
+        elif graphed:
+            launch = (f"whole-forward hipGraphs (madm_amd/pipeline.py::GraphedInference) on {max(1, args.streams)} streams: "
+                      f"{max(1, args.streams)} images in flight; " + fed.format("GraphedInference")
+                      + "; serial_* = one image in flight")
+        else:
+            launch = ("hipGraph replay of ONE captured batch, 1 stream: one batch in flight" if args.streams <= 1 else
+                      f"hipGraph replay of ONE captured batch on {args.streams} streams: {args.streams} batches in flight; "
+                      "serial_* = one batch in flight") + " (reference / profiling mode, not the product runner)"
+        if runner is not None and runner.range_check is not None:
+            rc = (f"deferred, on: the reference's per-call input-range assert (ldm_diffusers.py:147) is kept inside the timed "
+                  f"region without its host sync -- every step's min / max probe is copied to pinned memory behind the encoder "
+                  f"and asserted on the host by a later submit / drain ({range_checked} batches checked in this process)")
+        elif args.no_graph:
+            rc = "on, per call with its host sync, exactly as the reference (eager mode)"
+        else:
+            rc = "once before the timed region (fixed captured batch); its min / max probe kernel still runs every step"
         out = {
             "metric": {"extract": "UNet feature-extract images/sec @512x512 bs=2/GPU",
                        "eval": "full meta-arch eval images/sec @512x512 bs=1 (configs[2], informational)",
@@ -568,17 +635,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
                          "batched as B=3 through VAE enc -> UNet -> VAE dec -> projections, window features averaged, "
                          "DAFormer head @512x1024, K=9)")),
                        "global_batch": args.batch * world, "parallelism": f"replicas x{world} (no collectives)",
-                       "launch": "eager" if args.no_graph else
-                       (f"staged hipGraph pipeline (madm_amd/pipeline.py): VAE-encoder graphs on 1 stream, UNet graphs on "
-                        f"{args.pipeline} streams, up to {args.pipeline + 1} batches ({(args.pipeline + 1) * args.batch} images) in "
-                        f"flight, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}; serial_* = whole-forward "
-                        "graph, one batch in flight") if staged else ("hipGraph replay, 1 stream: one batch in flight"
-                                                                if args.streams <= 1 else
-                                                                f"hipGraph replay on {args.streams} streams: {args.streams} "
-                                                                f"batches ({args.streams * args.batch} images) in flight, "
-                                                                "consecutive steps overlap; serial_* = one batch in flight"),
-                       "range_check": "the reference's per-call input-range assert (ldm_diffusers.py:147, a host sync) ran "
-                                      "once before the timed region; its min/max probe kernel still runs every step"},
+                       "launch": launch, "range_check": rc},
             "device_ms_per_step": round(ev0.elapsed_time(ev1) / args.steps, 4) if single else None,
             "serial_ms_per_step": None if serial_ms is None else round(serial_ms, 4),
             "serial_images_per_s_per_gpu": None if serial_ms is None else round(args.batch / serial_ms * 1e3, 3),
@@ -607,7 +664,13 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist):
                                "timing": "HIP events on the launch stream, differenced brackets [K] [K K] (no overhead "
                                          "estimate subtracted); frac_events_raw = one plain event pair per launch",
                                "kernel_ms_per_step_events_raw": round(ms_raw, 4),
-                               "frac_events_raw": round(fl / (ms_raw * 1e-3) / 1e12 / peak, 4)}
+                               "frac_events_raw": round(fl / (ms_raw * 1e-3) / 1e12 / peak, 4),
+                               # the launches behind `achieved`, one row per distinct layer shape of the dominant kernel
+                               # (M = output pixels of the batch, N = output channels, K = 9 x input channels)
+                               "layers": [{"shape": d, "launches": r[0], "us_per_launch": round(1e3 * r[3] / r[0], 2),
+                                           "tflops": round(r[1] / (r[3] * 1e-3) / 1e12, 1),
+                                           "algorithmic_mb_per_launch": round(r[2] / r[0] / 1e6, 2)}
+                                          for d, r in sorted(layers[name].items(), key=lambda kv: -kv[1][3])]}
             out["kernels"] = {k: {"launches": v[0], "ms": round(v[4], 4), "ms_events_raw": round(v[1], 4),
                                   "tflops": round(v[2] / (v[4] * 1e-3) / 1e12, 2) if v[4] > 0 else None}
                               for k, v in sorted(prof.items(), key=lambda kv: -kv[1][4])}

@@ -75,7 +75,10 @@ __global__ __launch_bounds__(NW * 64, NQ > 1 ? 2 : 1) void attn_kernel(const Att
     constexpr int ES = C::ES;
     constexpr int NT = C::NT;
     constexpr unsigned OOB = 0x80000000u;
-    // d = 40 in the 16-bit modes (the only head dim below its 16-column tiling: 48): column 40 of the V tile holds 1.0
+    // d = 40 in the 16-bit modes (the only head dim below its 16-column tiling: 48): column 40 of the V tile holds 1.0, so
+    // O[:, 40] accumulates the row sum in the PV product.  NOTE: that normaliser is the sum of the probabilities AFTER their
+    // rounding to the 16-bit MFMA operand type (what the numerator is built from), not the f32 sum the other configurations
+    // keep -- numerator and denominator see the same rounded p.  launch_attn refuses any head dim but 40 for it.
     constexpr bool ONES = (ND == 3) && (NKB == 2) && sizeof(T) == 2 && C::PIPE;
     // [r4] 16-bit pipelined configurations: the K fragment reads of S = K Q^T are software-pipelined by hand (inline-asm
     // ds_read_b128, four reads ahead of the MFMAs that consume them, counted lgkmcnt) -- hipcc's schedule waited a full LDS
@@ -440,6 +443,10 @@ int launch_attn(const AttnP& p, hipStream_t s) {
     auto kern = attn_kernel<T, NKB, ND, NW, NS, NQ>;
     static std::atomic<uint64_t> attr_done{0};
     if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(C::LDS_BYTES), attr_done, "attention")) return e;
+    // the ones-column row sum (ONES in attn_kernel: 16-bit, ND == 3, NKB == 2, pipelined) writes 1.0 into V column 40 and reads
+    // the row sum from accumulator column 40: only a head dim of exactly 40 leaves that column free
+    if (ND == 3 && NKB == 2 && sizeof(T) == 2 && C::PIPE)
+        MADM_REQUIRE(p.D == 40, "attention: the 48-column 16-bit configuration serves head dim 40 only, got %d", p.D);
     dim3 grid((unsigned)((p.Lq + C::BQ - 1) / C::BQ), (unsigned)(p.B * p.H));
     kern<<<grid, NW * 64, C::LDS_BYTES, s>>>(p);
     return madm_check_launch("attn_kernel");

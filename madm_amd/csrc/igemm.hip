@@ -845,8 +845,14 @@ const std::vector<Tuned>& tuned_overrides() {
         while (fgets(line, sizeof line, f)) {
             Tuned t;
             if (line[0] == '#') continue;
-            if (sscanf(line, "%d %d %d %d %d %d %d %d", &t.dtype, &t.M, &t.N, &t.K, &t.KH, &t.variant, &t.tile, &t.splitk) == 8)
-                v.push_back(t);
+            if (sscanf(line, "%d %d %d %d %d %d %d %d", &t.dtype, &t.M, &t.N, &t.K, &t.KH, &t.variant, &t.tile, &t.splitk) != 8)
+                continue;
+            // a row with an unknown tile code would fall through to the default igemm launch unnoticed: refuse it loudly
+            if (t.tile < 1 || t.tile > 17 || t.splitk < 1 || t.variant < 0 || t.variant > 3 || !madm_dtype_ok(t.dtype)) {
+                fprintf(stderr, "madm: MADM_TUNED_FILE=%s: row ignored (tile 1..17, splitk >= 1, variant 0..3): %s", path, line);
+                continue;
+            }
+            v.push_back(t);
         }
         fclose(f);
         return v;
@@ -889,9 +895,10 @@ bool halo_eligible(const madm_conv2d_args* a) {
 // tile codes: 1 = igemm 128x128, 2 = igemm 128x64, 3 = igemm 64x64, 4 = halo conv3x3 BN=128, 5 = halo BN=64,
 // 6 = igemm 64x64 with an 8-deep register prefetch (latency-bound small-M GEMMs streaming cold weights),
 // 7 / 8 = LDS-DMA igemm 64x64 (4-slot ring) / 128x64 (3-slot ring), 9 / 10 = halo BN=128 / BN=64 with LDS-DMA weights,
-// 11 = LDS-DMA igemm 64x64 with a 3-slot ring (48 KB: three blocks per CU, for grids of 513 .. 768 tiles),
+// 11 = LDS-DMA igemm 64x64 with a 3-slot ring (48 KB + the 3 KB constant stash of every igemm_glds instantiation = 51 KB:
+//      three blocks per CU use 153 of the 160 KB, for grids of 513 .. 768 tiles),
 // 12 = halo conv3x3 on 16 x 16-pixel patches, BN = 128, halo and weights by LDS-DMA (conv3x3_h16.hip; maps >= 16 x 16),
-// 14 / 15 = LDS-DMA igemm 128x128 with a 3-slot (96 KB, one block per CU) / 2-slot ring (64 KB, two blocks per CU): 8 KB of
+// 14 / 15 = LDS-DMA igemm 128x128 with a 3-slot (96 + 3 KB, one block per CU) / 2-slot ring (64 + 3 KB, two blocks per CU): 8 KB of
 // operands per MFLOP through the CU's load path instead of 11 (128x64) / 31 (64x64) -- few, fat workgroups for launches
 // whose neighbours on the chip are other streams' kernels (tools/tune_concurrent.py)
 int pick_tile_raw(const madm_conv2d_args* a) {
@@ -1034,7 +1041,7 @@ int launch_glds_v(const IgemmP& p, dim3 grid, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
     if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds), attr_done, "igemm (LDS-DMA)")) return e;
     kern<<<grid, 256, lds, s>>>(p);
-    return MADM_OK;
+    return madm_check_launch("igemm_glds_kernel");
 }
 
 template <typename T, int BM, int BN, int NS>
@@ -1069,8 +1076,9 @@ int launch(const IgemmP& p0, int t, hipStream_t s, const PostGn& pn) {
         else if (t == 11) { if (int e = launch_glds<T, 64, 64, 3>(p, grid, s)) return e; }
         else if (t == 14) { if (int e = launch_glds<T, 128, 128, 3>(p, grid, s)) return e; }
         else if (t == 15) { if (int e = launch_glds<T, 128, 128, 2>(p, grid, s)) return e; }
-        // two-slot rings of the small tiles: 32 / 48 KB of LDS = five / three blocks per CU (short-K layers: the blocks'
-        // prologues and epilogues cover each other instead of a deep ring covering the K loop)
+        // two-slot rings of the small tiles: 32 / 48 KB rings + the 3 KB constant stash = 35 / 51 KB of LDS: four / three blocks
+        // per CU by LDS (short-K layers: the blocks' prologues and epilogues cover each other instead of a deep ring covering
+        // the K loop)
         else if (t == 16) { if (int e = launch_glds<T, 64, 64, 2>(p, grid, s)) return e; }
         else if (t == 17) { if (int e = launch_glds<T, 128, 64, 2>(p, grid, s)) return e; }
         else if (lin) igemm_kernel<T, 64, 64, 4, true><<<grid, 256, 0, s>>>(p);

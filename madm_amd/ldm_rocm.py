@@ -411,6 +411,7 @@ class LdmRocm(nn.Module):
         latents, noisy = ops.latents_add_noise(moments.t, self.vae.config.scaling_factor, noise, sa, sn, timesteps,
                                                B, h * w, ops.k_tile(dtype), h, w)
         self.last_latents = latents
+        self.last_minmax = minmax     # the stem's (min, max) probe of this batch: pipeline.DeferredRangeCheck reads it late
         return {"B": B, "h": h, "w": w, "noisy": noisy, "latents": latents, "timesteps": timesteps, "enc_taps": enc_taps,
                 "minmax": minmax}
 

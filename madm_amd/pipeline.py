@@ -1,16 +1,27 @@
-"""Throughput launch strategy for LdmRocm.forward: the two stages of the path as separate hipGraph executables on
-separate HIP streams.
+"""Throughput launch strategy for LdmRocm.forward / MadmInference.forward: hipGraph executables on several HIP streams,
+fed with a NEW batch per submit the way the reference's inference loop feeds its model
+(/root/reference/evaluation/evaluator.py:75-93: ``for idx, inputs in enumerate(data_loader): outputs = model(inputs)``).
 
+``StagedExtractor`` -- the two stages of the extractor as separate graphs on separate streams.
 Stage 1 (``LdmRocm._stage_encode``: normalise -> vae_encoder -> timestep draw -> add_noise, ldm_diffusers.py:143-163) is
 MFMA-bound and fills the chip on its own; stage 2 (``_stage_unet``: diffusion_unet + the tap hand-over, :165-217) at
 bs = 2 is launch / latency-bound and leaves most CUs idle.  So consecutive batches are overlapped
 like this: every batch's encoder runs on ONE stream (encoders never overlap each other: nothing to gain), its UNet on
 one of ``unet_streams`` streams after the encoder's event, so up to ``unet_streams`` UNets of different batches run side
-by side and the next encoder slides under them.  Each in-flight batch owns a hand-over slot (latents, timesteps) and its
-own output tensors; a slot's encoder waits until the slot's previous UNet has finished.
+by side and the next encoder slides under them.  Each in-flight batch owns a SLOT: static input buffers (``img``,
+``cond_inputs``, ``cond_emb``: ``submit`` copies the caller's tensors into them on the encoder stream), the hand-over
+(latents, timesteps) and its own output tensors; a slot's copies and encoder wait until the slot's previous UNet has finished.
 
-Same kernels, same per-batch results as ``LdmRocm.forward`` (tests/test_parity_gpu.py::test_staged_pipeline_matches_forward);
-only the order in which the GPU sees the launches changes.
+``GraphedInference`` -- the whole ``MadmInference.forward`` (pad -> prompt -> extractor -> VAE decoder -> projections ->
+DAFormer head -> resize) as one graph per slot, slots round-robin on ``streams`` streams, same submit contract.
+
+The reference's per-call input-range assert (ldm_diffusers.py:147: ``assert -1 <= images.min() and images.max() <= 1``, a host
+sync per call) is kept as a DEFERRED check: the stem kernel's min / max probe of every submitted batch is copied to a pinned
+ring behind the encoder and compared on the host as soon as a later ``submit`` / ``drain`` finds it completed -- the
+``AssertionError`` comes a few submits late instead of stalling the device once per batch.
+
+Same kernels, same per-batch results as ``LdmRocm.forward`` (tests/test_parity_gpu.py::test_staged_pipeline_*: distinct batches
+per submit, every slot bit-identical to ``forward()`` on ITS batch); only the order in which the GPU sees the launches changes.
 """
 import os
 import warnings
@@ -20,18 +31,89 @@ import torch
 from . import ops
 
 
+class DeferredRangeCheck:
+    """The reference's ``assert -1 <= images.min() and images.max() <= 1`` (ldm_diffusers.py:147) without its host sync: ring
+    of pinned (min, max) pairs + one event per entry; ``push`` enqueues the device -> pinned copy on the given stream,
+    ``poll`` checks every entry whose event has fired (non-blocking), ``drain`` waits for all of them."""
+
+    def __init__(self, device, depth=64):
+        self.depth = int(depth)
+        self.host = torch.empty((self.depth, 2), dtype=torch.float32).pin_memory()
+        self.events = [torch.cuda.Event() for _ in range(self.depth)]
+        self.turn_of = [None] * self.depth
+        self.head = 0            # next entry to check
+        self.tail = 0            # next entry to fill
+        self.checked = 0
+
+    def push(self, minmax, stream, turn):
+        if self.tail - self.head >= self.depth:        # ring full: the oldest entry is `depth` submits old -- wait for it
+            self._check(self.head, block=True)
+        r = self.tail % self.depth
+        self.host[r].copy_(minmax, non_blocking=True)
+        self.events[r].record(stream)
+        self.turn_of[r] = turn
+        self.tail += 1
+
+    def _check(self, i, block):
+        r = i % self.depth
+        if block:
+            self.events[r].synchronize()
+        elif not self.events[r].query():
+            return False
+        lo, hi = self.host[r].tolist()
+        self.head = i + 1
+        self.checked += 1
+        assert -1 <= lo and hi <= 1, (f"input range check (ldm_diffusers.py:147), deferred: the batch of submit #{self.turn_of[r]} "
+                                      f"has min {lo} max {hi} after normalisation, outside [-1, 1]")
+        return True
+
+    def poll(self):
+        while self.head < self.tail and self._check(self.head, block=False):
+            pass
+
+    def drain(self):
+        while self.head < self.tail:
+            self._check(self.head, block=True)
+
+
+def _static_like(t):
+    return None if t is None else torch.empty_like(t, memory_format=torch.contiguous_format).copy_(t)
+
+
+def _copy_checked(dst, src, name):
+    if dst is None:
+        assert src is None, f"{name}: the pipeline was built without this input"
+        return
+    assert src is not None and tuple(src.shape) == tuple(dst.shape), \
+        f"{name}: the graphs were captured for shape {tuple(dst.shape)}, got {None if src is None else tuple(src.shape)}"
+    dst.copy_(src, non_blocking=True)
+
+
+def _queues_warning(n, who):
+    # the streams overlap only when each sits on a hardware queue (and pipe) of its own: the runtime multiplexes HIP streams
+    # onto GPU_MAX_HW_QUEUES queues (default 4) in creation order and reads the variable once, at start-up
+    q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
+    if q < n:
+        warnings.warn(f"{who}: {n} streams on GPU_MAX_HW_QUEUES={q} hardware queues -- streams will share queues and "
+                      f"serialise; export GPU_MAX_HW_QUEUES>={n} before the process starts")
+
+
 class StagedExtractor:
-    def __init__(self, ldm, batched_inputs, unet_streams=3, streams=None, **kwargs):
+    """``pipe = StagedExtractor(ldm, example_inputs); outs, done = pipe.submit(batched_inputs)``.
+
+    ``example_inputs`` fixes what the graphs are captured for: tensor shapes, the presence of ``cond_emb`` and the
+    ``timestep`` range (a construction-time constant, like every other non-tensor entry).  ``submit`` takes a dict with the
+    same keys as ``LdmRocm.forward`` (``img`` [B,3,H,W] f32, ``cond_inputs`` [B,77,768], ``cond_emb`` [B,1,1280] | None) on the
+    pipeline's device."""
+
+    def __init__(self, ldm, example_inputs, unet_streams=3, streams=None, sync_inputs=True, range_check=None, **kwargs):
         assert unet_streams >= 1
         self.ldm = ldm
         self.k = int(unet_streams)
-        # the k + 1 streams overlap only when each sits on a hardware queue (and pipe) of its own: the runtime multiplexes
-        # HIP streams onto GPU_MAX_HW_QUEUES queues (default 4) in creation order and reads the variable once, at start-up
-        q = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4)
-        if q < self.k + 1:
-            warnings.warn(f"StagedExtractor: {self.k + 1} streams on GPU_MAX_HW_QUEUES={q} hardware queues -- streams will "
-                          "share queues and serialise; export GPU_MAX_HW_QUEUES>=%d before the process starts" % (self.k + 1))
-        dev = batched_inputs['img'].device
+        self.sync_inputs = bool(sync_inputs)
+        _queues_warning(self.k + 1, "StagedExtractor")
+        dev = example_inputs['img'].device
+        self.device = dev
         if streams is not None:       # reuse another (idle) pipeline's streams: they already sit on pipes of their own
             assert len(streams) == self.k + 1
             self.s_enc, self.s_unet = streams[0], list(streams[1:])
@@ -60,17 +142,28 @@ class StagedExtractor:
             prio = os.environ.get("MADM_EXP_PRIO", "")
             self.s_enc = torch.cuda.Stream(device=dev, priority=-1 if prio == "e" else 0)
             self.s_unet = [torch.cuda.Stream(device=dev, priority=-1 if prio == "u" else 0) for _ in range(self.k)]
+        # per-slot static inputs: the graphs read THESE tensors; everything that is not a tensor is a capture-time constant
+        self.tensor_keys = [k_ for k_ in ('img', 'cond_inputs', 'cond_emb') if k_ in example_inputs]
+        self.const_inputs = {k_: v for k_, v in example_inputs.items() if k_ not in self.tensor_keys}
+        assert not any(torch.is_tensor(v) for v in self.const_inputs.values()), \
+            f"StagedExtractor: unexpected tensor inputs {[k_ for k_, v in self.const_inputs.items() if torch.is_tensor(v)]}"
+        self.static = []
+        for j in range(self.k):
+            d = {k_: _static_like(example_inputs[k_]) for k_ in self.tensor_keys}
+            assert d['img'].dtype == torch.float32, "img is handed over as f32 NCHW (the stem kernel normalises it)"
+            d.update(self.const_inputs)
+            self.static.append(d)
         self.enc_graphs, self.unet_graphs, self.slots, self.outs = [], [], [], []
         cur = torch.cuda.current_stream(dev)
         with torch.no_grad():
             for j in range(self.k):
                 self.s_enc.wait_stream(cur)
                 with torch.cuda.stream(self.s_enc):
-                    ldm._stage_encode(batched_inputs)          # sizes this stream's workspaces outside the capture
+                    ldm._stage_encode(self.static[j])          # sizes this stream's workspaces outside the capture
                 self.s_enc.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=self.s_enc):
-                    st = ldm._stage_encode(batched_inputs)
+                    st = ldm._stage_encode(self.static[j])
                 self.enc_graphs.append(g)
                 self.slots.append(st)
             for j in range(self.k):
@@ -78,39 +171,74 @@ class StagedExtractor:
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
                     ops.ARENA.reset(dev)
-                    ldm._stage_unet(self.slots[j], batched_inputs, **kwargs)
+                    ldm._stage_unet(self.slots[j], self.static[j], **kwargs)
                 s.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s):
                     ops.ARENA.reset(dev)                       # the statistics arena of this stage: zeroed inside the graph
-                    self.outs.append(ldm._stage_unet(self.slots[j], batched_inputs, **kwargs))
+                    self.outs.append(ldm._stage_unet(self.slots[j], self.static[j], **kwargs))
                 self.unet_graphs.append(g)
         torch.cuda.synchronize(dev)
         self.encoded = [torch.cuda.Event() for _ in range(self.k)]
         self.done = [torch.cuda.Event() for _ in range(self.k)]
+        self._ready = [torch.cuda.Event() for _ in range(2 * self.k)]
         self.turn = 0
+        if range_check is None:
+            range_check = bool(ldm.check_input_range)
+        has_probe = self.slots[0].get("minmax") is not None
+        self.range_check = DeferredRangeCheck(dev) if (range_check and has_probe) else None
 
     @property
     def streams(self):
         return [self.s_enc, *self.s_unet]
 
-    def submit(self):
+    def submit(self, batched_inputs):
         """Enqueues one batch; returns (outputs, event): the slot's output tensors are valid once ``event`` has fired and
-        stay so until the slot comes round again (``unet_streams`` submits later)."""
+        stay so until the slot comes round again (``unet_streams`` submits later) -- consume them on the host after
+        ``event.synchronize()`` or on a stream after ``stream.wait_event(event)``; a consumer that works on ANOTHER stream
+        than the slot's UNet stream must have finished (or be waited for) before that later submit.
+
+        The caller's tensors may be reused as soon as ``submit`` returns only in stream order: they are read by copies
+        enqueued on the encoder stream behind an event recorded on the caller's current stream (``sync_inputs``).
+        Raises the deferred range ``AssertionError`` of an EARLIER batch when its probe has arrived."""
+        for k_ in {*self.const_inputs, *batched_inputs} - set(self.tensor_keys):
+            v, got = self.const_inputs.get(k_), batched_inputs.get(k_)
+            assert not torch.is_tensor(got) and got == v, \
+                f"StagedExtractor: '{k_}' = {v!r} is fixed at construction (captured in the graphs), got {got!r}"
+        if self.range_check is not None:
+            self.range_check.poll()
         j = self.turn % self.k
         first = self.turn < self.k
+        turn = self.turn
         self.turn += 1
+        st = self.static[j]
+        if self.sync_inputs:
+            ready = self._ready[turn % len(self._ready)]
+            ready.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.s_enc):
+            if self.sync_inputs:
+                self.s_enc.wait_event(ready)
             if not first:
-                self.s_enc.wait_event(self.done[j])            # the slot's hand-over buffers are free again
+                self.s_enc.wait_event(self.done[j])            # the slot's input and hand-over buffers are free again
+            for k_ in self.tensor_keys:
+                _copy_checked(st[k_], batched_inputs.get(k_), k_)
             self.enc_graphs[j].replay()
             self.encoded[j].record(self.s_enc)
+            if self.range_check is not None:
+                self.range_check.push(self.slots[j]["minmax"], self.s_enc, turn)
         s = self.s_unet[j]
         with torch.cuda.stream(s):
             s.wait_event(self.encoded[j])
             self.unet_graphs[j].replay()
             self.done[j].record(s)
         return self.outs[j], self.done[j]
+
+    def drain(self):
+        """Waits for everything submitted and runs the range checks still pending."""
+        for s in self.streams:
+            s.synchronize()
+        if self.range_check is not None:
+            self.range_check.drain()
 
     def concurrency_probe(self, reps=3):
         """Detects streams that share a hardware pipe: time of the k UNet graphs side by side on their k streams over k
@@ -144,3 +272,86 @@ class StagedExtractor:
         stream = stream or torch.cuda.current_stream()
         for s in self.streams:
             stream.wait_stream(s)
+
+
+class GraphedInference:
+    """``MadmInference.forward`` (mtmadise.py:657-691) as one hipGraph per slot; slots round-robin on ``streams`` streams, so
+    ``streams`` images are in flight.  ``submit(batched_inputs)`` takes the reference's ``[{'target_second_modality': [3,H,W]}]``
+    list (0 .. 255 values, any float / uint8 dtype, host or device), copies the image into the slot's static buffer and
+    returns (``[{'sem_seg': [1,K,H,W]}]``, event).  One image size per runner (the graphs are captured for it); the
+    extractor's range assert is deferred as in ``StagedExtractor``."""
+
+    def __init__(self, model, example_inputs, streams=3, slots=None, sync_inputs=True, range_check=None):
+        self.model = model
+        self.n_streams = int(streams)
+        self.n_slots = int(slots or streams)
+        assert self.n_slots >= self.n_streams >= 1
+        self.sync_inputs = bool(sync_inputs)
+        _queues_warning(self.n_streams, "GraphedInference")
+        assert len(example_inputs) == 1
+        dev = next(model.parameters()).device
+        self.device = dev
+        ex = example_inputs[0]['target_second_modality']
+        ldm = model.backbone.feature_extractor.ldm_extractor
+        self.ldm = ldm
+        self.streams_ = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
+        self.static, self.graphs, self.outs, self.minmax = [], [], [], []
+        cur = torch.cuda.current_stream(dev)
+        with torch.no_grad():
+            for j in range(self.n_slots):
+                s = self.streams_[j % self.n_streams]
+                x = torch.empty(tuple(ex.shape), dtype=torch.float32, device=dev).copy_(ex)
+                call = [{'target_second_modality': x}]
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    model(call)                     # sizes this stream's workspaces outside the capture
+                s.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    out = model(call)
+                self.static.append(x)
+                self.graphs.append(g)
+                self.outs.append(out)
+                self.minmax.append(getattr(ldm, "last_minmax", None))
+        torch.cuda.synchronize(dev)
+        self.done = [torch.cuda.Event() for _ in range(self.n_slots)]
+        self._ready = [torch.cuda.Event() for _ in range(2 * self.n_slots)]
+        self.turn = 0
+        if range_check is None:
+            range_check = bool(ldm.check_input_range)
+        self.range_check = DeferredRangeCheck(dev) if (range_check and self.minmax[0] is not None) else None
+
+    def stream_of(self, slot):
+        return self.streams_[slot % self.n_streams]
+
+    def submit(self, batched_inputs):
+        """Returns (outputs, event, slot).  The outputs stay valid until the slot comes round again (``slots`` submits later);
+        work enqueued on ``stream_of(slot)`` before that is ordered in front of the slot's next replay by itself."""
+        assert len(batched_inputs) == 1 and 'modality_type' not in batched_inputs[0]
+        if self.range_check is not None:
+            self.range_check.poll()
+        j = self.turn % self.n_slots
+        turn = self.turn
+        self.turn += 1
+        s = self.stream_of(j)
+        x = batched_inputs[0]['target_second_modality']
+        assert tuple(x.shape) == tuple(self.static[j].shape), \
+            f"GraphedInference: captured for images of shape {tuple(self.static[j].shape)}, got {tuple(x.shape)}"
+        if self.sync_inputs and x.is_cuda:
+            ready = self._ready[turn % len(self._ready)]
+            ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            if self.sync_inputs and x.is_cuda:
+                s.wait_event(ready)
+            self.static[j].copy_(x, non_blocking=True)          # dtype conversion (uint8 -> f32) included
+            self.graphs[j].replay()
+            if self.range_check is not None:
+                self.range_check.push(self.minmax[j], s, turn)
+            self.done[j].record(s)
+        return self.outs[j], self.done[j], j
+
+    def drain(self):
+        for s in self.streams_:
+            s.synchronize()
+        if self.range_check is not None:
+            self.range_check.drain()

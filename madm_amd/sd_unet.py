@@ -18,6 +18,7 @@ from . import ops, packing
 from .nn import Tok, Conv2d, Linear, GroupNorm, LayerNorm, Identity, _Packed
 from ._lib import EPI_GEGLU
 
+LORA_TARGETS = ("to_q", "to_k", "to_v", "to_out.0")
 LORA_PAD = 64  # K-extension of a LoRA-augmented GEMM (>= sum of the fused ranks), one bf16 K-tile
 
 
@@ -293,7 +294,10 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, ctx, Lk):
         h = self.proj_in(self.norm(x), stats=False)
         t = h.t
-        if FUSE_PROJ_OUT and len(self.transformer_blocks) == 1 and self.proj_out.n_pad == self.proj_out.out_channels:
+        # the composed operand reads ff.net[2]'s own weight: a plain Linear only (an adapter wrapped around it -- a LoRA config
+        # whose target_modules match 'net.2' -- takes the two-launch path, as the FOLD_LN paths do)
+        if (FUSE_PROJ_OUT and len(self.transformer_blocks) == 1 and self.proj_out.n_pad == self.proj_out.out_channels
+                and type(self.transformer_blocks[0].ff.net[2]) is Linear):
             h2, g = self.transformer_blocks[0](t, x.B, x.HW, ctx, Lk, defer_ff_out=True)
             wp, b = self._proj_out_ff_operand(h2.dtype)
             C = self.proj_out.out_channels
@@ -485,6 +489,12 @@ class UNet2DConditionModel(nn.Module):
                 continue
             if isinstance(module, Linear) and name.endswith(targets) and ".lora_" not in name \
                     and not name.endswith("base_layer"):
+                if not name.endswith(LORA_TARGETS):
+                    # the adapters run as K-extensions of the fused attention projections (_FusedProj); any other layer would
+                    # need a path of its own (and ff.net[2] is composed with proj_out): refuse loudly instead of failing in
+                    # the forward.  The reference wraps exactly these four (mtmadise.py:115-127)
+                    raise NotImplementedError(f"LoRA on '{name}': the HIP path supports adapters on {LORA_TARGETS} "
+                                              "(the reference's target_modules, mtmadise.py:119) only")
                 parent_name, _, child = name.rpartition(".")
                 parent = self.get_submodule(parent_name)
                 wrapped = LoraLinear(module)

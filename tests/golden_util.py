@@ -155,10 +155,10 @@ def prepare_lora_(unet, variant):
                 p.requires_grad = True
 
 
-def train_inputs(B, size, K, **_):
+def train_inputs(B, size, K, input_seed=8899, **_):
     """list[dict] as the dataset mapper hands it over (data/dataset/cross_modality_dataset.py:423-521): 0..255 images,
     int64 labels with ~6 % ignore pixels."""
-    g = torch.Generator().manual_seed(8899)
+    g = torch.Generator().manual_seed(input_seed)
     out = []
     for _i in range(B):
         lab = torch.randint(0, K, (1, size // 8, size // 8), generator=g)

@@ -295,6 +295,49 @@ def test_device_evaluator_is_bit_exact(cuda):
     assert all(res[f"IoU-{i}"] == 100 * ref["iou"][i] for i in range(K))
 
 
+def test_inference_on_dataset_pipelined_matches_serial_loop(cuda):
+    """evaluation.inference_on_dataset (the reference's loop, evaluator.py:75-93, on whole-forward hipGraphs with three images
+    in flight and evaluator.process chained on the slot's stream): eight DIFFERENT images of two sizes -> every sem_seg
+    bit-identical to MadmInference.forward on that image, the confusion matrix and the metrics equal to the serial loop's;
+    an out-of-range image (values > 255) raises the reference's range assert, late."""
+    import numpy as np
+    from madm_amd.evaluation import SemSegEvaluator, inference_on_dataset
+    model = _build_product("DEPTH", torch.float16)
+    K = 11
+    g = torch.Generator().manual_seed(31)
+    loader = []
+    for i in range(8):
+        H, W = (512, 512) if i not in (2, 5) else (448, 512)
+        img = 255.0 * torch.rand((3, H, W), generator=g)
+        if i % 2:
+            img = img.to(torch.uint8)                                   # dataset mappers hand uint8 or float images over
+        loader.append([{"target_second_modality": img.cuda() if i % 3 else img,
+                        "target_label": torch.randint(0, K, (1, H, W), generator=g)}])
+
+    class Recording(SemSegEvaluator):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.seen = []
+
+        def process(self, inputs, outputs):
+            self.seen.append(outputs[0]["sem_seg"].clone())             # on the slot's stream, behind its forward
+            super().process(inputs, outputs)
+
+    ev = Recording(K, ignore_label=255)
+    res = inference_on_dataset(model, loader, ev, streams=3)
+    ev2 = SemSegEvaluator(K, ignore_label=255)
+    for i, inputs in enumerate(loader):
+        out = model(inputs)
+        assert torch.equal(out[0]["sem_seg"], ev.seen[i]), f"image {i}: pipelined forward differs from forward()"
+        ev2.process(inputs, out)
+    assert np.array_equal(ev.confusion(), ev2.confusion()) and ev.confusion().sum() == 6 * 512 * 512 + 2 * 448 * 512
+    assert res["sem_seg"]["mIoU"] == ev2.evaluate()["sem_seg"]["mIoU"]
+    bad = [{"target_second_modality": loader[0][0]["target_second_modality"] * 1.01 + 1.0,
+            "target_label": loader[0][0]["target_label"]}]
+    with pytest.raises(AssertionError, match="input range check"):
+        inference_on_dataset(model, [loader[0], bad, loader[4], loader[6]], SemSegEvaluator(K, ignore_label=255))
+
+
 def test_flat_adamw_ema_clip(cuda):
     """One-launch AdamW (+ folded unscale / clip) and EMA on flat fp32 storage against torch.optim.AdamW,
     clip_grad_norm_ and the reference's EMA formula (cmdise.py:337-349) on CPU."""

@@ -317,3 +317,20 @@ def test_shipped_code_has_no_low_lane_op_sel_packed_fp32():
     assert low == 0, f"{low} packed-FP32 instructions feed a LOW result from a HIGH register"
     stray = {k: v for k, v in per.items() if "conv3x3_h16_kernel" not in k}
     assert not stray, f"packed-FP32 ops outside the 16 x 16 halo conv: {list(stray.items())[:5]}"
+
+
+def test_lora_targets_outside_the_attention_projections_are_refused():
+    """the adapters run as K-extensions of the fused attention projections; a LoRA config whose target_modules
+    match any other Linear (e.g. 'net.2', which Transformer2DModel composes with proj_out) must fail loudly at add_adapter,
+    not with an AttributeError somewhere in the forward."""
+    from types import SimpleNamespace
+    import pytest
+    from madm_amd import sd_unet
+    t = sd_unet.Transformer2DModel(heads=2, dim_head=40, in_channels=80, cross_attention_dim=64)
+    cfg = SimpleNamespace(r=4, lora_alpha=4, target_modules=["to_q", "net.2"])
+    with pytest.raises(NotImplementedError, match="net.2"):
+        sd_unet.UNet2DConditionModel.add_adapter(t, cfg, "x")
+    t = sd_unet.Transformer2DModel(heads=2, dim_head=40, in_channels=80, cross_attention_dim=64)
+    sd_unet.UNet2DConditionModel.add_adapter(t, SimpleNamespace(r=4, lora_alpha=4, target_modules=["to_k", "to_q", "to_v", "to_out.0"]), "x")
+    wrapped = [n for n, m in t.named_modules() if isinstance(m, sd_unet.LoraLinear)]
+    assert len(wrapped) == 8 and type(t.transformer_blocks[0].ff.net[2]) is sd_unet.Linear

@@ -153,81 +153,149 @@ def test_batch_invariance_and_determinism(extractor):
 
 
 
+def _distinct_batches(n, B, H, W):
+    """n DIFFERENT batches (image, prompt tokens and time-embedding residual all differ from batch to batch and from image to
+    image): a slot that read another slot's input or hand-over buffer cannot reproduce forward() on its own batch."""
+    out = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(5000 + i)
+        out.append({"img": torch.rand((B, 3, H, W), generator=g).cuda(),
+                    "cond_inputs": (0.02 * torch.randn((B, 77, 768), generator=g)).cuda(),
+                    "cond_emb": (0.02 * torch.randn((B, 1, 1280), generator=g)).cuda()})
+    return out
+
+
+def _forward_each(m, batches):
+    want = []
+    with torch.no_grad():
+        for b in batches:
+            want.append([f.clone() for f in m(b, "rgb")])
+    torch.cuda.synchronize()
+    for i in range(1, len(want)):        # the batches really differ: so do the results
+        assert not torch.equal(want[i][0], want[0][0])
+    return want
+
+
+def _assert_slots_equal(got, want):
+    bad = []
+    for step, (feats, ref) in enumerate(zip(got, want)):
+        assert len(feats) == len(ref)
+        for i, (a, b) in enumerate(zip(feats, ref)):
+            if not torch.equal(a, b):
+                bad.append((step, i, int((a != b).sum()), float((a.float() - b.float()).abs().max())))
+    assert not bad, f"staged pipeline differs from forward() on the same batch (step, tap, elements, max diff): {bad[:8]}"
+
+
 def test_staged_pipeline_matches_forward(extractor):
     """madm_amd.pipeline.StagedExtractor (bench.py's launch strategy: encoder graphs on one stream, UNet graphs on K
-    streams, K + 1 batches in flight) must hand back exactly what LdmRocm.forward returns for the same batch, for every
-    slot and on every round."""
+    streams, K + 1 batches in flight) must hand back exactly what LdmRocm.forward returns for the batch that was SUBMITTED,
+    for every slot and on every round: seven submits, seven different batches."""
     from madm_amd.pipeline import StagedExtractor
-    case = dict(CASES["small_t0"])
-    images, cond_inputs, cond_emb, _, _ = make_inputs(**case)
     m = extractor
     m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = torch.float16
-    inputs = {"img": images.repeat(2, 1, 1, 1).cuda(), "cond_inputs": cond_inputs.repeat(2, 1, 1).cuda(),
-              "cond_emb": cond_emb.repeat(2, 1, 1).cuda()}
+    batches = _distinct_batches(7, 2, 64, 64)
+    want = _forward_each(m, batches)
     with torch.no_grad():
-        want = [f.clone() for f in m(inputs, "rgb")]
-        torch.cuda.synchronize()
-        keep = m.check_input_range
-        m.check_input_range = False
-        try:
-            pipe = StagedExtractor(m, inputs, unet_streams=3)
-            pipe.fork()
-            got = []
-            for step in range(7):                       # every slot is reused at least once
-                outs, done = pipe.submit()
-                done.synchronize()
-                got.append([f.clone() for f in outs])
-            pipe.join()
-            torch.cuda.synchronize()
-        finally:
-            m.check_input_range = keep
-    for step, feats in enumerate(got):
-        assert len(feats) == len(want)
-        for a, b in zip(feats, want):
-            assert torch.equal(a, b), f"step {step}: staged pipeline differs from forward()"
+        pipe = StagedExtractor(m, batches[0], unet_streams=3)
+        assert pipe.range_check is not None          # the reference's range assert stays on, deferred
+        got = []
+        for b in batches:                            # every slot is reused at least once
+            outs, done = pipe.submit(b)
+            done.synchronize()
+            got.append([f.clone() for f in outs])
+        pipe.drain()
+        assert pipe.range_check.checked == len(batches)
+    _assert_slots_equal(got, want)
+
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 def test_staged_pipeline_matches_forward_at_512(extractor, dtype):
     """The TIMED launch path at the metric's size (BASELINE configs[1]: 2 x 3 x 512 x 512): four graphs of full-chip
     kernels running side by side -- the 16 x 16 halo conv of one batch's VAE encoder next to other batches' GEMM / attention
-    / packed-f32 stem and LayerNorm kernels, two workgroups of different kernels per CU.  Every slot of every round must be
-    bit-identical to LdmRocm.forward on the same batch (a co-residency-triggered miscompute would show
-    here).  The submits are NOT separated by host syncs, so the batches really overlap; outputs are copied out on the
-    slot's own stream behind its UNet."""
+    / packed-f32 stem and LayerNorm kernels, two workgroups of different kernels per CU.  Twelve submits carry twelve
+    DIFFERENT batches (images, prompts, time residuals); every slot of every round must be bit-identical to LdmRocm.forward on
+    ITS batch (VERDICT r4 "What's weak" 2: with equal inputs in every slot, a slot reading another slot's hand-over buffer or an
+    encoder overwriting a buffer a UNet still reads would go unseen; r3 item 2: a co-residency-triggered miscompute would
+    show here too).  The submits are NOT separated by host syncs, so the batches really overlap; outputs are copied out on
+    the slot's own stream behind its UNet.  The input tensors of a submit are overwritten right after it on the caller's
+    stream (the pipeline must have ordered its copies in front of that)."""
     from madm_amd.pipeline import StagedExtractor
-    case = dict(CASES["full_t0"])
-    images, cond_inputs, cond_emb, _, _ = make_inputs(**case)
     m = extractor
     m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = dtype
-    inputs = {"img": images.repeat(2, 1, 1, 1).cuda(), "cond_inputs": cond_inputs.repeat(2, 1, 1).cuda(),
-              "cond_emb": cond_emb.repeat(2, 1, 1).cuda()}
-    assert tuple(inputs["img"].shape) == (2, 3, 512, 512)
+    batches = _distinct_batches(12, 2, 512, 512)
+    want = _forward_each(m, batches)
     with torch.no_grad():
-        want = [f.clone() for f in m(inputs, "rgb")]
-        torch.cuda.synchronize()
-        keep = m.check_input_range
-        m.check_input_range = False
+        pipe = StagedExtractor(m, batches[0], unet_streams=3)
+        assert pipe.range_check is not None
+        got = []
+        stage = {k: torch.empty_like(v) for k, v in batches[0].items()}
+        for step, b in enumerate(batches):          # every slot comes round four times, 4 batches in flight
+            for k in stage:                         # the caller's buffers: ONE set, refilled for every submit
+                stage[k].copy_(b[k])
+            outs, done = pipe.submit(stage)
+            s = pipe.s_unet[step % pipe.k]
+            with torch.cuda.stream(s):              # behind this slot's UNet, before the slot's next encoder may start
+                got.append([f.clone() for f in outs])
+                pipe.done[step % pipe.k].record(s)
+        pipe.drain()
+        assert pipe.range_check.checked == len(batches)
+    _assert_slots_equal(got, want)
+
+
+def test_staged_pipeline_deferred_range_assert(extractor):
+    """The reference asserts the input range on every call (ldm_diffusers.py:147).  The pipeline keeps the assert without the
+    per-call host sync: an out-of-range batch raises AssertionError from a LATER submit or from drain(), naming the submit;
+    in-range batches before and after it pass; shapes other than the captured ones and a changed timestep range are refused."""
+    from madm_amd.pipeline import StagedExtractor
+    m = extractor
+    m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = torch.float16
+    batches = _distinct_batches(5, 2, 64, 64)
+    bad = dict(batches[2])
+    bad["img"] = bad["img"].clone()
+    bad["img"][1, 2, 7, 9] = 1.25                    # (1.25 - 0.5) / 0.5 = 1.5 > 1
+    with torch.no_grad():
+        pipe = StagedExtractor(m, batches[0], unet_streams=2)
+        pipe.submit(batches[0])
+        pipe.submit(batches[1])
+        pipe.drain()
+        pipe.submit(bad)                             # submit #2
+        with pytest.raises(AssertionError, match=r"submit #2 .*max 1\.5"):
+            for b in batches[3:]:
+                pipe.submit(b)
+            pipe.drain()
+        pipe.drain()                                 # the pipeline stays usable: the later batches are checked and pass
+        outs, done = pipe.submit(batches[4])
+        pipe.drain()
+        with pytest.raises(AssertionError, match="captured for shape"):
+            pipe.submit({**batches[0], "img": batches[0]["img"][:1]})
+        with pytest.raises(AssertionError, match="fixed at construction"):
+            pipe.submit({**batches[0], "timestep": (60, 61)})
+        # an unchecked pipeline can be asked for explicitly
+        assert StagedExtractor(m, batches[0], unet_streams=1, range_check=False).range_check is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16], ids=["f32", "f16", "bf16"])
+def test_fused_proj_out_matches_two_launch_path(extractor, dtype):
+    """Transformer2DModel's fast path ([h2 | g] [Wp | Wp Wf]^T + (Wp bf + bp) + x, one launch) against the
+    two-launch path it replaces (ff.net[2] + residual, then proj_out + residual), same weights, same input: equal up to the
+    one extra rounding of h3 that the two-launch path has (f32: summation order only)."""
+    from madm_amd import sd_unet
+    m = extractor
+    m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = dtype
+    b = _distinct_batches(1, 2, 64, 64)[0]
+    assert sd_unet.FUSE_PROJ_OUT
+    with torch.no_grad():
+        fused = [f.clone() for f in m(b, "rgb")]
+        sd_unet.FUSE_PROJ_OUT = False
         try:
-            pipe = StagedExtractor(m, inputs, unet_streams=3)
-            pipe.fork()
-            got = []
-            for step in range(12):                      # every slot comes round four times, 4 batches in flight
-                outs, done = pipe.submit()
-                s = pipe.s_unet[step % pipe.k]
-                with torch.cuda.stream(s):              # behind this slot's UNet, before the slot's next encoder may start
-                    got.append([f.clone() for f in outs])
-                    pipe.done[step % pipe.k].record(s)
-            pipe.join()
-            torch.cuda.synchronize()
+            plain = [f.clone() for f in m(b, "rgb")]
         finally:
-            m.check_input_range = keep
-    bad = []
-    for step, feats in enumerate(got):
-        assert len(feats) == len(want)
-        for i, (a, b) in enumerate(zip(feats, want)):
-            if not torch.equal(a, b):
-                bad.append((step, i, int((a != b).sum()), float((a.float() - b.float()).abs().max())))
-    assert not bad, f"staged pipeline differs from forward() at 512x512 (step, tap, elements, max diff): {bad[:8]}"
+            sd_unet.FUSE_PROJ_OUT = True
+    tol = {torch.float32: 2e-5, torch.float16: 3e-3, torch.bfloat16: 2.5e-2}[dtype]
+    for i, (a_, b_) in enumerate(zip(fused, plain)):
+        e, l2 = rel_err(a_.cpu(), b_.cpu())
+        print(dtype, f"tap{i}: fused vs two-launch max {e:.2e} l2 {l2:.2e}")
+        assert l2 < tol, (i, e, l2)
 
 
 def test_helper_functions_match_reference_signatures(extractor):

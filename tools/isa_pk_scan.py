@@ -3,10 +3,14 @@
 
 On MI355X a `v_pk_add_f32 ... op_sel:[0,1]` (the LOW result takes its operand from the HIGH register of the pair) delivered
 the low result with that operand read as 0 in lanes 48..63, intermittently, when a second wave on the SIMD was in an MFMA loop
-(instrumented kernel, tools/exp/pkf32_check.py).  The library is therefore built without packed-FP32 ops
-(csrc/Makefile: -target-feature -packed-fp32-ops); this script proves it on the binary:
+(instrumented kernel, tools/exp/pkf32_check.py).  Every kernel file but conv3x3_h16.hip is therefore built without
+packed-FP32 ops (csrc/Makefile: -target-feature -packed-fp32-ops); the 16 x 16 halo conv keeps them (30 % of its time) and
+its code holds only the op_sel_hi broadcast forms.  This script proves both facts on the binary -- the rule of
+tests/test_host.py::test_shipped_code_has_no_low_lane_op_sel_packed_fp32:
 
-    isa_pk_scan.py <libmadm_hip.so | file.s ...>      exit status 1 when a packed-FP32 instruction is found
+    isa_pk_scan.py <libmadm_hip.so | file.s ...>      exit status 1 when a packed-FP32 instruction feeds a LOW result from
+                                                      a HIGH register, or sits outside conv3x3_h16_kernel
+    isa_pk_scan.py --strict ...                       exit status 1 on ANY packed-FP32 instruction (the no-packed build)
 
 For .so / .o inputs the gfx950 code objects are cut out of the clang offload bundle and disassembled with llvm-objdump."""
 import os
@@ -76,12 +80,18 @@ def scan(path):
     return total, low, per
 
 
+ALLOWED = "conv3x3_h16_kernel"     # the one kernel that keeps packed FP32 (op_sel_hi forms only)
+
 if __name__ == "__main__":
     bad = 0
-    for p in sys.argv[1:]:
+    args = [a for a in sys.argv[1:] if a != "--strict"]
+    strict = len(args) != len(sys.argv) - 1
+    for p in args:
         total, low, per = scan(p)
-        print(f"{p}: {total} packed-FP32 VALU instructions ({low} of them feed a LOW result from a HIGH register) in {len(per)} kernels")
+        outside = {k: v for k, v in per.items() if ALLOWED not in k}
+        print(f"{p}: {total} packed-FP32 VALU instructions ({low} of them feed a LOW result from a HIGH register) in {len(per)} "
+              f"kernels, {sum(outside.values())} outside {ALLOWED}")
         for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:6]:
             print(f"   {v:6d}  {k[:100]}")
-        bad += total
+        bad += total if strict else low + sum(outside.values())
     sys.exit(1 if bad else 0)
