@@ -76,17 +76,32 @@ class DeferredRangeCheck:
             self._check(self.head, block=True)
 
 
+class Submitted(tuple):
+    """What ``submit`` returns: unpacks as ``(outputs, done)`` (``GraphedInference``: ``(outputs, done, slot)``);
+    ``.taken`` is the event behind the pipeline's copies of the caller's input tensors -- the caller may OVERWRITE those
+    tensors once it has fired (``stream.wait_event(r.taken)`` / ``r.taken.synchronize()``), exactly as the source of any
+    asynchronous copy; merely dropping them is safe at once (the copies are registered with the caching allocator);
+    ``.turn`` numbers the submit (the deferred range assert names it)."""
+
+    def __new__(cls, items, taken, turn):
+        self = super().__new__(cls, items)
+        self.taken, self.turn = taken, turn
+        return self
+
+
 def _static_like(t):
     return None if t is None else torch.empty_like(t, memory_format=torch.contiguous_format).copy_(t)
 
 
-def _copy_checked(dst, src, name):
+def _copy_checked(dst, src, name, stream):
     if dst is None:
         assert src is None, f"{name}: the pipeline was built without this input"
         return
     assert src is not None and tuple(src.shape) == tuple(dst.shape), \
         f"{name}: the graphs were captured for shape {tuple(dst.shape)}, got {None if src is None else tuple(src.shape)}"
     dst.copy_(src, non_blocking=True)
+    if src.is_cuda:
+        src.record_stream(stream)      # a caller that drops the tensor now must not see its memory reused under the copy
 
 
 def _queues_warning(n, who):
@@ -182,6 +197,7 @@ class StagedExtractor:
         self.encoded = [torch.cuda.Event() for _ in range(self.k)]
         self.done = [torch.cuda.Event() for _ in range(self.k)]
         self._ready = [torch.cuda.Event() for _ in range(2 * self.k)]
+        self._taken = [torch.cuda.Event() for _ in range(2 * self.k)]
         self.turn = 0
         if range_check is None:
             range_check = bool(ldm.check_input_range)
@@ -193,13 +209,14 @@ class StagedExtractor:
         return [self.s_enc, *self.s_unet]
 
     def submit(self, batched_inputs):
-        """Enqueues one batch; returns (outputs, event): the slot's output tensors are valid once ``event`` has fired and
-        stay so until the slot comes round again (``unet_streams`` submits later) -- consume them on the host after
+        """Enqueues one batch; returns ``Submitted`` = (outputs, event): the slot's output tensors are valid once ``event`` has
+        fired and stay so until the slot comes round again (``unet_streams`` submits later) -- consume them on the host after
         ``event.synchronize()`` or on a stream after ``stream.wait_event(event)``; a consumer that works on ANOTHER stream
         than the slot's UNet stream must have finished (or be waited for) before that later submit.
 
-        The caller's tensors may be reused as soon as ``submit`` returns only in stream order: they are read by copies
-        enqueued on the encoder stream behind an event recorded on the caller's current stream (``sync_inputs``).
+        The caller's tensors are read by copies enqueued on the ENCODER stream, behind an event recorded on the caller's
+        current stream (``sync_inputs``: whatever produced them there is finished first).  Like the source of any asynchronous
+        copy they must not be overwritten before the copies ran: ``.taken`` of the result fires then (dropping them is safe).
         Raises the deferred range ``AssertionError`` of an EARLIER batch when its probe has arrived."""
         for k_ in {*self.const_inputs, *batched_inputs} - set(self.tensor_keys):
             v, got = self.const_inputs.get(k_), batched_inputs.get(k_)
@@ -221,7 +238,9 @@ class StagedExtractor:
             if not first:
                 self.s_enc.wait_event(self.done[j])            # the slot's input and hand-over buffers are free again
             for k_ in self.tensor_keys:
-                _copy_checked(st[k_], batched_inputs.get(k_), k_)
+                _copy_checked(st[k_], batched_inputs.get(k_), k_, self.s_enc)
+            taken = self._taken[turn % len(self._taken)]
+            taken.record(self.s_enc)
             self.enc_graphs[j].replay()
             self.encoded[j].record(self.s_enc)
             if self.range_check is not None:
@@ -231,7 +250,7 @@ class StagedExtractor:
             s.wait_event(self.encoded[j])
             self.unet_graphs[j].replay()
             self.done[j].record(s)
-        return self.outs[j], self.done[j]
+        return Submitted((self.outs[j], self.done[j]), taken, turn)
 
     def drain(self):
         """Waits for everything submitted and runs the range checks still pending."""
@@ -316,6 +335,7 @@ class GraphedInference:
         torch.cuda.synchronize(dev)
         self.done = [torch.cuda.Event() for _ in range(self.n_slots)]
         self._ready = [torch.cuda.Event() for _ in range(2 * self.n_slots)]
+        self._taken = [torch.cuda.Event() for _ in range(2 * self.n_slots)]
         self.turn = 0
         if range_check is None:
             range_check = bool(ldm.check_input_range)
@@ -325,8 +345,9 @@ class GraphedInference:
         return self.streams_[slot % self.n_streams]
 
     def submit(self, batched_inputs):
-        """Returns (outputs, event, slot).  The outputs stay valid until the slot comes round again (``slots`` submits later);
-        work enqueued on ``stream_of(slot)`` before that is ordered in front of the slot's next replay by itself."""
+        """Returns ``Submitted`` = (outputs, event, slot).  The outputs stay valid until the slot comes round again (``slots``
+        submits later); work enqueued on ``stream_of(slot)`` before that is ordered in front of the slot's next replay by
+        itself.  A device image must not be overwritten before ``.taken`` of the result has fired (see ``Submitted``)."""
         assert len(batched_inputs) == 1 and 'modality_type' not in batched_inputs[0]
         if self.range_check is not None:
             self.range_check.poll()
@@ -344,11 +365,15 @@ class GraphedInference:
             if self.sync_inputs and x.is_cuda:
                 s.wait_event(ready)
             self.static[j].copy_(x, non_blocking=True)          # dtype conversion (uint8 -> f32) included
+            if x.is_cuda:
+                x.record_stream(s)
+            taken = self._taken[turn % len(self._taken)]
+            taken.record(s)
             self.graphs[j].replay()
             if self.range_check is not None:
                 self.range_check.push(self.minmax[j], s, turn)
             self.done[j].record(s)
-        return self.outs[j], self.done[j], j
+        return Submitted((self.outs[j], self.done[j], j), taken, turn)
 
     def drain(self):
         for s in self.streams_:
