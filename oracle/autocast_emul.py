@@ -63,6 +63,64 @@ class CudaAutocastF16(TorchFunctionMode):
         return func(*args, **kwargs)
 
 
+# ---- Winograd F(2 x 2, 3 x 3) in the 16-bit mode: what would it cost in accuracy?   ----------
+_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+_BT = torch.tensor([[1.0, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+_AT = torch.tensor([[1.0, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+
+
+def winograd_conv3x3_f16(x, w, bias=None, operand_dtype=_LOW):
+    """3 x 3 / stride 1 / pad 1 convolution as a 16-bit MFMA kernel would run Winograd F(2 x 2, 3 x 3) (Lavin & Gray 2016):
+    the transformed weight U = G g G^T is formed once from the f16 weight (f64) and ROUNDED to the operand type (cached at
+    pack time); the transformed input V = B^T d B is formed from the f16 activations in f32 (exact: four signed terms) and
+    ROUNDED to the operand type; the 16 per-position products accumulate in f32 (exact products of 16-bit operands); the
+    output transform A^T M A runs in f32; one rounding of the result to f16.  The direct form rounds NEITHER operand again:
+    products of the stored f16 values accumulate exactly -- that difference is what this function measures."""
+    B, C, H, W = x.shape
+    N = w.shape[0]
+    assert H % 2 == 0 and W % 2 == 0 and tuple(w.shape[1:]) == (C, 3, 3)
+    xh = x.to(_LOW).float()
+    U = (_G @ w.to(_LOW).double() @ _G.T).float().to(operand_dtype).float()                     # [N, C, 4, 4]
+    d = F.pad(xh, (1, 1, 1, 1)).unfold(2, 4, 2).unfold(3, 4, 2)                                 # [B, C, H/2, W/2, 4, 4]
+    V = (_BT @ d @ _BT.T).to(operand_dtype).float()
+    th, tw = H // 2, W // 2
+    M = torch.einsum("bcijxy,ncxy->bnijxy", V, U)                                               # f32 accumulation over c
+    Y = _AT @ M @ _AT.T                                                                         # [B, N, th, tw, 2, 2]
+    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(B, N, H, W)
+    if bias is not None:
+        y = y + bias.float().view(1, -1, 1, 1)
+    return y.to(_LOW)
+
+
+class CudaAutocastF16Winograd(CudaAutocastF16):
+    """CudaAutocastF16 with every eligible convolution (3 x 3, stride 1, pad 1, Cin in ``cins``, maps of at least ``min_hw``
+    pixels a side) computed by ``winograd_conv3x3_f16``; ``self.hits`` lists what was replaced.  The SD VAE's 3 x 3 convs have
+    128 / 256 / 512 input channels, the UNet's none of these."""
+
+    def __init__(self, cins=(128, 256), min_hw=256, operand_dtype=_LOW):
+        super().__init__()
+        self.cins, self.min_hw, self.operand_dtype = set(cins), min_hw, operand_dtype
+        self.hits = []
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in (F.conv2d, torch.conv2d):
+            names = ("input", "weight", "bias", "stride", "padding", "dilation", "groups")
+            a = dict(zip(names, args))
+            a.update(kwargs)
+            x, w = a["input"], a["weight"]
+
+            def one(v, d):
+                v = a.get(v, d)
+                return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+            if (tuple(w.shape[2:]) == (3, 3) and one("stride", 1) == (1, 1) and one("padding", 0) == (1, 1)
+                    and one("dilation", 1) == (1, 1) and a.get("groups", 1) == 1 and w.shape[1] in self.cins
+                    and min(x.shape[2:]) >= self.min_hw):
+                self.hits.append((tuple(x.shape), w.shape[0]))
+                return winograd_conv3x3_f16(x, w, a.get("bias"), self.operand_dtype)
+        return super().__torch_function__(func, types, args, kwargs)
+
+
 @torch.no_grad()
 def half_parameters_(module):
     """Parameters and buffers rounded to fp16 VALUES (``torch_dtype=torch.float16`` of ldm_diffusers.py:248,253-255)."""

@@ -114,7 +114,12 @@ def label_inputs(B, K, H, W, **_):
 
 # ---- one training step of the shipped RGB->Depth configuration at 64 x 64 (tests/golden/train_depth.npz) --------------
 TRAIN_CASE = dict(B=2, size=64, K=11, py_seed=20240, np_seed=20241, full_grad_max_numel=70000,
-                  pseudo_threshold=0.25)     # low threshold: random-weight teachers are never 96.8 % confident
+                  pseudo_threshold=0.25,     # low threshold: random-weight teachers are never 96.8 % confident
+                  # the input seed is chosen so that NO teacher decision of any variant sits within fp32 noise of its
+                  # discontinuity (tools/exp/scan_train_fixture_seed.py): smallest top-2 probability gap / distance
+                  # of a max-probability to the threshold over the 8 192 pixels: depth 1.8e-5 / 2.1e-5, event 7.4e-5 / 6.0e-5,
+                  # lora 9.5e-6 / 1.05e-5 (the round-2..4 seed 8899: 3.3e-6 / 3.9e-6, 1.5e-5 / 1.9e-6, 8.8e-7 / 1.06e-6)
+                  input_seed=8908)
 # model arguments of the shipped task configs (config_files/SemSeg/MTMADISE/*.py) that differ between the fixtures
 TRAIN_VARIANTS = {
     "train_depth": dict(vae_decoder_loss='st', vae_decoder_loss_weight=[1.0, 1.0], denoise_timestep_range=[60, 61],
@@ -155,7 +160,7 @@ def prepare_lora_(unet, variant):
                 p.requires_grad = True
 
 
-def train_inputs(B, size, K, input_seed=8899, **_):
+def train_inputs(B, size, K, input_seed, **_):
     """list[dict] as the dataset mapper hands it over (data/dataset/cross_modality_dataset.py:423-521): 0..255 images,
     int64 labels with ~6 % ignore pixels."""
     g = torch.Generator().manual_seed(input_seed)
@@ -169,6 +174,20 @@ def train_inputs(B, size, K, input_seed=8899, **_):
                     "target_second_modality": 255.0 * torch.rand((3, size, size), generator=g),
                     "width": size, "height": size})
     return out
+
+
+TIE_BAND = 1.5e-6      # what fp32 summation order can move a teacher probability by (f32 forward parity: 2 .. 6e-6 of the
+# logits' magnitude, tests/test_parity_gpu.py)
+
+
+def fixture_decision_margins(gold, size, pseudo_threshold):
+    """From the fixture's own teacher logits: per pixel, the gap between the two largest class probabilities (an argmax tie
+    flips the pseudo label) and the distance of the largest one to the confidence threshold (a crossing moves pseudo_weight
+    by 1 / pixels) -- mtmadise.py:339-349.  A build may legitimately differ from the fixture only at pixels whose margin is
+    inside TIE_BAND; with no such pixel the labels must be exact and the losses meet the tight gate."""
+    x = torch.nn.functional.interpolate(gold["ema_logits"], size=(size, size), mode="bilinear", align_corners=False)
+    top = torch.softmax(x.double(), dim=1).topk(2, dim=1).values
+    return top[:, 0] - top[:, 1], (top[:, 0] - pseudo_threshold).abs()
 
 
 def train_palette(K):

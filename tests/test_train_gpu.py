@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from golden_util import (TRAIN_CASE, TRAIN_VARIANTS, train_inputs, train_palette, train_dropout_scales, grad_probe, init_eval_params,
+from golden_util import (TRAIN_CASE, TRAIN_VARIANTS, TIE_BAND, fixture_decision_margins, train_inputs, train_palette, train_dropout_scales, grad_probe, init_eval_params,
                          load_golden, model_args, prepare_lora_)
 from util import rel_err, to_tokens, from_tokens
 
@@ -256,37 +256,42 @@ def test_train_step_matches_fixture(cuda, variant, dtype):
             p.grad.div_(gscale)
     f32 = dtype == torch.float32
     ltol = 1e-4 if f32 else (1e-2 if dtype == torch.float16 else 5e-2)
-    # Discontinuities of the step: the teacher's argmax (two classes tying to ~1e-7) and its confidence threshold (a
-    # probability within ~1e-7 of pseudo_threshold: pseudo_weight = share of the pixels above it moves by 1 / pixels).  The
-    # device and the CPU oracle sum in different orders, so such a pixel may fall the other way, and everything computed from
-    # the mixed labels / the weight (the two target-side losses, their gradients) then legitimately differs by that pixel's
-    # share: ~3e-4 of vae_decoder_target_loss for ONE pixel of the colour-label image.  The lora fixture holds such a pixel
-    # (measured round 4: builds that differ only in instruction selection land on either side of it: 0.194513 with one label
-    # flip against the stored array, 0.194572 with none -- the fixture's loss and its stored label array sit on different
-    # sides).  So: at most 2 flipped pixels / threshold crossings, and the TARGET-side losses are gated at 1e-3 in f32.
-    flips = int((model.last_step["pseudo_label"].cpu().to(torch.uint8) != gold["pseudo_label"]).sum())
+    # Discontinuities of the step: the teacher's argmax (two classes tying) and its confidence threshold (pseudo_weight =
+    # share of the pixels above it moves by 1 / pixels per crossing).  The device and the CPU oracle sum in different orders, so
+    # a pixel whose decision margin is inside fp32 noise may fall the other way, and everything computed from the mixed labels
+    # / the weight (the two target-side losses, their gradients) then legitimately differs by that pixel's share.  Whether the
+    # fixture HOLDS such pixels is read from the fixture itself (its teacher logits), not from the build under test
+    # (ADVICE r4): the allowance -- label flips only AT those pixels, at most that many threshold crossings, target-side
+    # losses at 1e-3 -- exists only then.  The round-5 fixtures were regenerated with an input seed that has none
+    # (golden_util.TRAIN_CASE: smallest margins 9.5e-6 .. 7.4e-5), so every variant runs the tight gates: exact labels, 1e-4.
+    gap, thr_margin = fixture_decision_margins(gold, TRAIN_CASE["size"], TRAIN_CASE["pseudo_threshold"])
+    tie_px = (gap < TIE_BAND)
+    thr_px = int((thr_margin < TIE_BAND).sum())
+    near_tie = f32 and (int(tie_px.sum()) + thr_px > 0)
+    print(f"fixture decision margins: min top-2 gap {gap.min().item():.2e}, min |p - threshold| {thr_margin.min().item():.2e}; "
+          f"{int(tie_px.sum())} / {thr_px} pixels inside the fp32 band {TIE_BAND:g}")
     npix = gold["pseudo_label"].numel()          # the weight is ONE share over the whole batch (dacs_transforms / labels.py:38)
-    quanta = float((model.last_step["mixed_seg_weight"].cpu() - gold["mixed_seg_weight"]).abs().max()) * npix
-    # (... seen where the mix mask takes the target image; the weight itself is compared as well)
-    quanta = max(quanta, abs(model.last_step["pseudo_weight"].flatten()[0].item() - gold["pseudo_weight0"].item()) * npix)
-    near_tie = f32 and (flips > 0 or quanta > 0.5)
-    if near_tie:
-        print(f"near-tie pixels: {flips} label flips, {quanta:.3f} threshold crossings (of {npix} pixels)")
-        assert flips <= 2 and quanta < 2.01 and abs(quanta - round(quanta)) < 0.02
+    if f32:
+        flipped = model.last_step["pseudo_label"].cpu().to(torch.uint8) != gold["pseudo_label"]
+        assert not bool((flipped & ~tie_px).any()), \
+            f"{int((flipped & ~tie_px).sum())} pseudo labels differ where the fixture's argmax margin is decisive"
+        quanta = float((model.last_step["mixed_seg_weight"].cpu() - gold["mixed_seg_weight"]).abs().max()) * npix
+        quanta = max(quanta, abs(model.last_step["pseudo_weight"].flatten()[0].item() - gold["pseudo_weight0"].item()) * npix)
+        assert quanta < thr_px + 0.01, f"{quanta:.3f} threshold crossings, the fixture allows {thr_px}"
     rep = []
     for k, v in losses.items():
         ref = gold["loss_" + k].item()
         rep.append(f"{k} {v.item():.6f} / {ref:.6f}")
-        tol_k = 1e-3 if (f32 and "target" in k) else ltol
+        tol_k = 1e-3 if (near_tie and "target" in k) else ltol
         assert abs(v.item() - ref) <= tol_k * max(abs(ref), 1e-3), rep[-1]
     print(dtype, "; ".join(rep))
     ls = model.last_step
     if f32:
-        # index work is bit-exact GIVEN its inputs; the argmax of the teacher's f32 probabilities may flip where two classes
-        # tie to ~1e-7 (the device and the CPU oracle sum in different orders): at most 2 of the 8 192 pixels
-        for key in ("pseudo_label", "mixed_lbl"):
-            flips = int((ls[key].cpu().to(torch.uint8) != gold[key]).sum())
-            assert flips <= 2, (key, flips)
+        # index work is bit-exact GIVEN its inputs (the pseudo labels were compared above, pixel by pixel against the
+        # fixture's decision margins); the mixed labels follow from them through the class-mix masks
+        n_tie = int(tie_px.sum())
+        flips = int((ls["mixed_lbl"].cpu().to(torch.uint8) != gold["mixed_lbl"]).sum())
+        assert flips <= n_tie, ("mixed_lbl", flips, n_tie)
         if not near_tie:
             assert abs(ls["pseudo_weight"].flatten()[0].item() - gold["pseudo_weight0"].item()) < 1e-6
             assert rel_err(ls["mixed_seg_weight"].cpu(), gold["mixed_seg_weight"])[0] < 1e-6
@@ -422,10 +427,12 @@ def test_trainer_step_with_lora_adapters_only(cuda):
     torch.cuda.synchronize()
     assert stepped and norm > 0 and losses["zero_grad"] == 0.0
     gold = load_golden("train_depth_lora_only")
-    # (target-side losses at 1e-3: this fixture holds a pseudo-label pixel within ~1e-7 of the confidence threshold, see
-    # test_train_step_matches_fixture -- builds that differ in instruction selection land on either side of it)
+    # (target-side losses at 1e-3 only if the fixture holds a teacher decision inside fp32 noise -- read from the fixture, see
+    # test_train_step_matches_fixture; the round-5 fixtures hold none)
+    gap, thr_margin = fixture_decision_margins(gold, TRAIN_CASE["size"], TRAIN_CASE["pseudo_threshold"])
+    near_tie = bool((gap < TIE_BAND).any() or (thr_margin < TIE_BAND).any())
     for k in ("source_loss", "target_loss", "vae_decoder_source_loss", "vae_decoder_target_loss"):
-        tol_k = 1e-3 if "target" in k else 1e-4
+        tol_k = 1e-3 if (near_tie and "target" in k) else 1e-4
         assert abs(losses[k] - gold["loss_" + k].item()) <= tol_k * abs(gold["loss_" + k].item()), k
     moved = {"default": 0, "Depth": 0, "Event": 0}
     for n, p in model.named_parameters():

@@ -18,11 +18,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def run_all(case_name, unet_weights="f16", threads=None, variants=(False, True)):
-    """-> {f32_schedule: (rows, seconds)} and the fp32 oracle's seconds; ONE model build and ONE fp32 reference run."""
+    """-> {variant: (rows, seconds)} and the fp32 oracle's seconds; ONE model build and ONE fp32 reference run.
+    variant: False / True = add_noise coefficients in fp16 (the reference) / fp32; ("wino", cins, min_hw[, operand dtype]) =
+    the fp32-schedule variant with the VAE's eligible 3 x 3 convs as 16-bit Winograd F(2 x 2, 3 x 3) (oracle/autocast_emul.py)."""
     from golden_util import CASES, make_inputs
     from madm_amd import weights
     from oracle import sd_modules, ldm_path
-    from oracle.autocast_emul import CudaAutocastF16, half_parameters_
+    from oracle.autocast_emul import CudaAutocastF16, CudaAutocastF16Winograd, half_parameters_
     if threads:
         torch.set_num_threads(threads)
     case = CASES[case_name]
@@ -48,9 +50,15 @@ def run_all(case_name, unet_weights="f16", threads=None, variants=(False, True))
     out = {}
     for f32_schedule in variants:
         t0 = time.time()
-        with torch.no_grad(), CudaAutocastF16():
+        mode = CudaAutocastF16()
+        if isinstance(f32_schedule, tuple):
+            mode = CudaAutocastF16Winograd(cins=f32_schedule[1], min_hw=f32_schedule[2],
+                                           operand_dtype=f32_schedule[3] if len(f32_schedule) > 3 else torch.float16)
+        with torch.no_grad(), mode:
             emu = ldm_path.ldm_forward(vae, unet, _F32Schedule() if f32_schedule else sched, noise, images, cond, cond_emb,
                                        timesteps=timesteps)
+        if isinstance(f32_schedule, tuple):
+            print(f"# {f32_schedule}: {len(mode.hits)} convs ran as Winograd: {sorted(set(mode.hits))}", flush=True)
         rows = []
         pairs = [("latents", emu["latents"], ref["latents"]), ("sample", emu["sample"], ref["sample"])]
         pairs += [(f"tap{i}", a, b) for i, (a, b) in enumerate(zip(emu["unet_features"], ref["unet_features"]))]
@@ -71,7 +79,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", default="full_t0")
     ap.add_argument("--unet-weights", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--winograd", action="store_true",
+                    help="columns: fp32-schedule baseline; + Winograd F(2x2,3x3) on the VAE convs with 128 / 256 input channels at "
+                         ">= 256 x 256 (the 16 x 16 halo kernel's layers); + on every 3 x 3 VAE conv; + the same with bf16 operands")
     args = ap.parse_args()
+    if args.winograd:
+        variants = (True, ("wino", (128, 256), 256), ("wino", (128, 256, 512), 64), ("wino", (128, 256), 256, torch.bfloat16))
+        out, t_ref = run_all(args.case, args.unet_weights, variants=variants)
+        print(f"case {args.case}: relative L2 (max rel) against the fp32 oracle; columns: {variants}")
+        for i in range(len(out[True][0])):
+            name = out[True][0][i][0]
+            print(f"{name:10s} " + "   ".join(f"{out[v][0][i][2]:.3e} ({out[v][0][i][3]:.3e})" for v in variants))
+        return
     out, t_ref = run_all(args.case, args.unet_weights)
     for f32_schedule in (False, True):
         rows, t_emu = out[f32_schedule]
