@@ -74,6 +74,12 @@ def parse():
                          "encoder on one stream, its UNet on one of K streams, so K UNets of consecutive batches run side by "
                          "side and the next encoder slides under them; K + 1 batches in flight).  0 = whole-forward graphs "
                          "round-robin on --streams streams (the round-1 launch)")
+    ap.add_argument("--slots", type=int, default=6,
+                    help="extract workload: in-flight slots of the staged pipeline (0 = one per UNet stream).  More slots than "
+                         "streams let the in-order encoder stream run ahead instead of waiting for the UNet of three submits ago: "
+                         "same box, images/s at 3 / 4 / 5 / 6 slots: 358.7 / 348.8 / 365.8 / 363.1; a slower box at 3 / 5 / 7 / 8 / "
+                         "9 / 11: 351.8 / 355.2 / 349.0 / 356.7 / 355.2 / 356.0 (profiles/round5_ab_slots.txt); 2 x streams keeps "
+                         "the slot -> stream map balanced")
     ap.add_argument("--hw-queues", type=int, default=8,
                     help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime default of 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -481,7 +487,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
         from madm_amd.pipeline import StagedExtractor
         # A/B switches for the cost of the product API's per-submit work: MADM_EXP_NO_SYNC_INPUTS=1
         # drops the caller-stream event, MADM_EXP_NO_RANGE=1 the deferred range check
-        runner = pipe = StagedExtractor(ldm, pool[0], unet_streams=args.pipeline,
+        runner = pipe = StagedExtractor(ldm, pool[0], unet_streams=args.pipeline, slots=args.slots or None,
                                         sync_inputs=not int(os.environ.get("MADM_EXP_NO_SYNC_INPUTS", "0")),
                                         range_check=False if int(os.environ.get("MADM_EXP_NO_RANGE", "0")) else None)
 
@@ -564,7 +570,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
                          device=device)
             m2(*call)
             torch.cuda.synchronize()
-            pipe2 = StagedExtractor(m2, pool[0], unet_streams=args.pipeline, streams=pipe.streams)
+            pipe2 = StagedExtractor(m2, pool[0], unet_streams=args.pipeline, streams=pipe.streams, slots=args.slots or None)
             for i in range(args.warmup):
                 pipe2.submit(pool[i % len(pool)])
             torch.cuda.synchronize()
@@ -596,7 +602,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
             launch = "eager launches, a different seeded batch per step"
         elif staged:
             launch = (f"staged hipGraph pipeline (madm_amd/pipeline.py): VAE-encoder graphs on 1 stream, UNet graphs on "
-                      f"{args.pipeline} streams, up to {args.pipeline + 1} batches ({(args.pipeline + 1) * args.batch} images) in "
+                      f"{args.pipeline} streams, {pipe.n_slots} slots, up to {pipe.n_slots + 1} batches ({(pipe.n_slots + 1) * args.batch} images) in "
                       f"flight, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}; "
                       + fed.format("StagedExtractor") + "; serial_* = whole-forward graph, one batch in flight")
         elif graphed:

@@ -121,10 +121,15 @@ class StagedExtractor:
     same keys as ``LdmRocm.forward`` (``img`` [B,3,H,W] f32, ``cond_inputs`` [B,77,768], ``cond_emb`` [B,1,1280] | None) on the
     pipeline's device."""
 
-    def __init__(self, ldm, example_inputs, unet_streams=3, streams=None, sync_inputs=True, range_check=None, **kwargs):
+    def __init__(self, ldm, example_inputs, unet_streams=3, streams=None, sync_inputs=True, range_check=None, slots=None,
+                 **kwargs):
         assert unet_streams >= 1
         self.ldm = ldm
         self.k = int(unet_streams)
+        # slots >= UNet streams: slot j's UNet runs on stream j mod k; with more slots than streams the encoder stream may run
+        # further ahead of the UNets (a slot's encoder waits for that slot's previous UNet only)
+        self.n_slots = int(slots or unet_streams)
+        assert self.n_slots >= self.k
         self.sync_inputs = bool(sync_inputs)
         _queues_warning(self.k + 1, "StagedExtractor")
         dev = example_inputs['img'].device
@@ -163,7 +168,7 @@ class StagedExtractor:
         assert not any(torch.is_tensor(v) for v in self.const_inputs.values()), \
             f"StagedExtractor: unexpected tensor inputs {[k_ for k_, v in self.const_inputs.items() if torch.is_tensor(v)]}"
         self.static = []
-        for j in range(self.k):
+        for j in range(self.n_slots):
             d = {k_: _static_like(example_inputs[k_]) for k_ in self.tensor_keys}
             assert d['img'].dtype == torch.float32, "img is handed over as f32 NCHW (the stem kernel normalises it)"
             d.update(self.const_inputs)
@@ -171,7 +176,7 @@ class StagedExtractor:
         self.enc_graphs, self.unet_graphs, self.slots, self.outs = [], [], [], []
         cur = torch.cuda.current_stream(dev)
         with torch.no_grad():
-            for j in range(self.k):
+            for j in range(self.n_slots):
                 self.s_enc.wait_stream(cur)
                 with torch.cuda.stream(self.s_enc):
                     ldm._stage_encode(self.static[j])          # sizes this stream's workspaces outside the capture
@@ -181,8 +186,8 @@ class StagedExtractor:
                     st = ldm._stage_encode(self.static[j])
                 self.enc_graphs.append(g)
                 self.slots.append(st)
-            for j in range(self.k):
-                s = self.s_unet[j]
+            for j in range(self.n_slots):
+                s = self.s_unet[j % self.k]
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
                     ops.ARENA.reset(dev)
@@ -194,10 +199,10 @@ class StagedExtractor:
                     self.outs.append(ldm._stage_unet(self.slots[j], self.static[j], **kwargs))
                 self.unet_graphs.append(g)
         torch.cuda.synchronize(dev)
-        self.encoded = [torch.cuda.Event() for _ in range(self.k)]
-        self.done = [torch.cuda.Event() for _ in range(self.k)]
-        self._ready = [torch.cuda.Event() for _ in range(2 * self.k)]
-        self._taken = [torch.cuda.Event() for _ in range(2 * self.k)]
+        self.encoded = [torch.cuda.Event() for _ in range(self.n_slots)]
+        self.done = [torch.cuda.Event() for _ in range(self.n_slots)]
+        self._ready = [torch.cuda.Event() for _ in range(2 * self.n_slots)]
+        self._taken = [torch.cuda.Event() for _ in range(2 * self.n_slots)]
         self.turn = 0
         if range_check is None:
             range_check = bool(ldm.check_input_range)
@@ -210,7 +215,7 @@ class StagedExtractor:
 
     def submit(self, batched_inputs):
         """Enqueues one batch; returns ``Submitted`` = (outputs, event): the slot's output tensors are valid once ``event`` has
-        fired and stay so until the slot comes round again (``unet_streams`` submits later) -- consume them on the host after
+        fired and stay so until the slot comes round again (``slots`` submits later; default = ``unet_streams``) -- consume them on the host after
         ``event.synchronize()`` or on a stream after ``stream.wait_event(event)``; a consumer that works on ANOTHER stream
         than the slot's UNet stream must have finished (or be waited for) before that later submit.
 
@@ -224,8 +229,8 @@ class StagedExtractor:
                 f"StagedExtractor: '{k_}' = {v!r} is fixed at construction (captured in the graphs), got {got!r}"
         if self.range_check is not None:
             self.range_check.poll()
-        j = self.turn % self.k
-        first = self.turn < self.k
+        j = self.turn % self.n_slots
+        first = self.turn < self.n_slots
         turn = self.turn
         self.turn += 1
         st = self.static[j]
@@ -245,7 +250,7 @@ class StagedExtractor:
             self.encoded[j].record(self.s_enc)
             if self.range_check is not None:
                 self.range_check.push(self.slots[j]["minmax"], self.s_enc, turn)
-        s = self.s_unet[j]
+        s = self.s_unet[j % self.k]
         with torch.cuda.stream(s):
             s.wait_event(self.encoded[j])
             self.unet_graphs[j].replay()

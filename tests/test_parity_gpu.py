@@ -186,17 +186,19 @@ def _assert_slots_equal(got, want):
     assert not bad, f"staged pipeline differs from forward() on the same batch (step, tap, elements, max diff): {bad[:8]}"
 
 
-def test_staged_pipeline_matches_forward(extractor):
+@pytest.mark.parametrize("slots", [None, 5], ids=["slots3", "slots5"])
+def test_staged_pipeline_matches_forward(extractor, slots):
     """madm_amd.pipeline.StagedExtractor (bench.py's launch strategy: encoder graphs on one stream, UNet graphs on K
     streams, K + 1 batches in flight) must hand back exactly what LdmRocm.forward returns for the batch that was SUBMITTED,
-    for every slot and on every round: seven submits, seven different batches."""
+    for every slot and on every round: seven submits, seven different batches (``slots5``: more slots than UNet streams, two
+    slots share a stream and its split-K workspace)."""
     from madm_amd.pipeline import StagedExtractor
     m = extractor
     m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = torch.float16
     batches = _distinct_batches(7, 2, 64, 64)
     want = _forward_each(m, batches)
     with torch.no_grad():
-        pipe = StagedExtractor(m, batches[0], unet_streams=3)
+        pipe = StagedExtractor(m, batches[0], unet_streams=3, slots=slots)
         assert pipe.range_check is not None          # the reference's range assert stays on, deferred
         got = []
         for b in batches:                            # every slot is reused at least once
@@ -226,23 +228,24 @@ def test_staged_pipeline_matches_forward_at_512(extractor, dtype):
     batches = _distinct_batches(12, 2, 512, 512)
     want = _forward_each(m, batches)
     with torch.no_grad():
-        pipe = StagedExtractor(m, batches[0], unet_streams=3)
+        pipe = StagedExtractor(m, batches[0], unet_streams=3, slots=6)       # bench.py's configuration
         assert pipe.range_check is not None
         got = []
         stage = {k: torch.empty_like(v) for k, v in batches[0].items()}
         cur = torch.cuda.current_stream()
         taken = None
-        for step, b in enumerate(batches):          # every slot comes round four times, 4 batches in flight
+        for step, b in enumerate(batches):          # every slot comes round twice, up to 7 batches in flight
             if taken is not None:
                 cur.wait_event(taken)               # the source of an asynchronous copy: refill it once it has been read
             for k in stage:                         # the caller's buffers: ONE set, refilled for every submit
                 stage[k].copy_(b[k])
             sub = pipe.submit(stage)
             (outs, done), taken = sub, sub.taken
-            s = pipe.s_unet[step % pipe.k]
+            slot = step % pipe.n_slots
+            s = pipe.s_unet[slot % pipe.k]
             with torch.cuda.stream(s):              # behind this slot's UNet, before the slot's next encoder may start
                 got.append([f.clone() for f in outs])
-                pipe.done[step % pipe.k].record(s)
+                pipe.done[slot].record(s)
         pipe.drain()
         assert pipe.range_check.checked == len(batches)
     _assert_slots_equal(got, want)
