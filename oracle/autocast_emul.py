@@ -43,6 +43,39 @@ def _sdpa(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False, scale=None, *
     return (p.to(_LOW).float() @ v).to(_LOW)
 
 
+# ---- block-scaled fp8 (OCP MX, e4m3) for the PV product of attention: what would it cost in accuracy?   -----
+def mx_quantize_e4m3(x, dim, block=32):
+    """OCP microscaling: along ``dim``, every ``block`` consecutive elements share one power-of-two scale
+    2^(floor(log2(amax)) - 8) (E8M0; 8 = the largest e4m3 exponent) and are stored as e4m3 (3 mantissa bits, max 448, saturating)
+    -- what v_mfma_scale_f32_16x16x128_f8f6f4 consumes: 32 K-elements and one scale byte per lane.  Returns the dequantised
+    values in f32 (the instruction multiplies elements and scales exactly and accumulates in f32)."""
+    x = x.float().movedim(dim, -1)
+    shp = x.shape
+    L = shp[-1]
+    pad = (-L) % block
+    xb = F.pad(x, (0, pad)).reshape(*shp[:-1], (L + pad) // block, block)
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    e = torch.floor(torch.log2(torch.clamp(amax, min=2.0 ** -120))) - 8.0
+    scale = torch.exp2(e)
+    q = torch.clamp(xb / scale, -448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
+    q = torch.where(amax > 0, q, torch.zeros_like(q))
+    return q.reshape(*shp[:-1], L + pad)[..., :L].movedim(-1, dim)
+
+
+def sdpa_fp8_pv(q, k, v, scale=None):
+    """scaled_dot_product_attention as the f16 flash kernel computes it, except that the PV product takes block-scaled e4m3
+    operands: P (probabilities relative to the running row maximum, <= 1) quantised per (query, 32-key block), V per (32-key
+    block, channel); S = QK^T stays f16 x f16 -> f32 (d = 40 does not fill a K = 128 instruction).  The row sum is taken from
+    the QUANTISED probabilities (numerator and denominator see the same p, as the ones-column normaliser of attention.hip does)."""
+    q, k, v = _h(q).float(), _h(k).float(), _h(v).float()
+    scale = q.shape[-1] ** -0.5 if scale is None else scale
+    s_ = (q @ k.transpose(-1, -2)) * scale
+    p = torch.exp(s_ - s_.amax(dim=-1, keepdim=True))
+    pq = mx_quantize_e4m3(p, dim=-1)
+    vq = mx_quantize_e4m3(v, dim=-2)
+    return ((pq @ vq) / pq.sum(dim=-1, keepdim=True)).to(_LOW)
+
+
 class CudaAutocastF16(TorchFunctionMode):
     """``with CudaAutocastF16(): module(x)`` -- see the module docstring."""
 
@@ -50,9 +83,16 @@ class CudaAutocastF16(TorchFunctionMode):
              torch.Tensor.bmm, torch.mm}
     FP32 = {F.group_norm, torch.group_norm, F.layer_norm, torch.layer_norm, F.softmax, torch.softmax, torch.Tensor.softmax}
 
+    fp8_pv_min_keys = None      # set to a key count: self-attention launches with at least that many keys take sdpa_fp8_pv
+    fp8_hits = 0
+
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         if func is F.scaled_dot_product_attention:
+            q, k = args[0], args[1]
+            if self.fp8_pv_min_keys is not None and k.shape[-2] >= self.fp8_pv_min_keys and q.shape[-2] == k.shape[-2]:
+                self.fp8_hits += 1
+                return sdpa_fp8_pv(args[0], args[1], args[2], kwargs.get("scale"))
             return _sdpa(*args, **kwargs)
         if func in self.LOWER:
             a = [_h(x).float() if torch.is_tensor(x) and x.is_floating_point() else x for x in args]

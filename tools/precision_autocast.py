@@ -51,13 +51,17 @@ def run_all(case_name, unet_weights="f16", threads=None, variants=(False, True))
     for f32_schedule in variants:
         t0 = time.time()
         mode = CudaAutocastF16()
-        if isinstance(f32_schedule, tuple):
+        if isinstance(f32_schedule, tuple) and f32_schedule[0] == "fp8pv":
+            mode.fp8_pv_min_keys = f32_schedule[1]
+        elif isinstance(f32_schedule, tuple):
             mode = CudaAutocastF16Winograd(cins=f32_schedule[1], min_hw=f32_schedule[2],
                                            operand_dtype=f32_schedule[3] if len(f32_schedule) > 3 else torch.float16)
         with torch.no_grad(), mode:
             emu = ldm_path.ldm_forward(vae, unet, _F32Schedule() if f32_schedule else sched, noise, images, cond, cond_emb,
                                        timesteps=timesteps)
-        if isinstance(f32_schedule, tuple):
+        if isinstance(f32_schedule, tuple) and f32_schedule[0] == "fp8pv":
+            print(f"# {f32_schedule}: {mode.fp8_hits} self-attention calls ran their PV product in block-scaled e4m3", flush=True)
+        elif isinstance(f32_schedule, tuple):
             print(f"# {f32_schedule}: {len(mode.hits)} convs ran as Winograd: {sorted(set(mode.hits))}", flush=True)
         rows = []
         pairs = [("latents", emu["latents"], ref["latents"]), ("sample", emu["sample"], ref["sample"])]
@@ -82,7 +86,18 @@ def main():
     ap.add_argument("--winograd", action="store_true",
                     help="columns: fp32-schedule baseline; + Winograd F(2x2,3x3) on the VAE convs with 128 / 256 input channels at "
                          ">= 256 x 256 (the 16 x 16 halo kernel's layers); + on every 3 x 3 VAE conv; + the same with bf16 operands")
+    ap.add_argument("--fp8-pv", action="store_true",
+                    help="columns: fp32-schedule baseline; + the PV product of the 64 x 64 level's self-attention (4096 keys, the "
+                         "five launches that are 0.45 ms of the step) in block-scaled e4m3; + of every self-attention (>= 64 keys)")
     args = ap.parse_args()
+    if args.fp8_pv:
+        variants = (True, ("fp8pv", 4096), ("fp8pv", 64))
+        out, t_ref = run_all(args.case, args.unet_weights, variants=variants)
+        print(f"case {args.case}: relative L2 (max rel) against the fp32 oracle; columns: {variants}")
+        for i in range(len(out[True][0])):
+            name = out[True][0][i][0]
+            print(f"{name:10s} " + "   ".join(f"{out[v][0][i][2]:.3e} ({out[v][0][i][3]:.3e})" for v in variants))
+        return
     if args.winograd:
         variants = (True, ("wino", (128, 256), 256), ("wino", (128, 256, 512), 64), ("wino", (128, 256), 256, torch.bfloat16))
         out, t_ref = run_all(args.case, args.unet_weights, variants=variants)
