@@ -80,6 +80,10 @@ def parse():
                          "same box, images/s at 3 / 4 / 5 / 6 slots: 358.7 / 348.8 / 365.8 / 363.1; a slower box at 3 / 5 / 7 / 8 / "
                          "9 / 11: 351.8 / 355.2 / 349.0 / 356.7 / 355.2 / 356.0 (profiles/round5_ab_slots.txt); 2 x streams keeps "
                          "the slot -> stream map balanced")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="extract workload, informational: the input pool lives in PINNED HOST memory and every submit transfers "
+                         "its batch over PCIe (the contract's `value` is measured with the inputs resident in HBM; this is the "
+                         "PCIe-inclusive rate DESIGN.md section 6 quotes)")
     ap.add_argument("--hw-queues", type=int, default=8,
                     help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime default of 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -409,7 +413,10 @@ def main():
         model.unet.set_adapter(["Depth"])
         weights.randomize_lora_B_(model.unet)
     pool = make_input_pool(args.batch, args.size, device)
-    return run(args, model, (pool[0], "rgb"), model, rank, world, device, dist, mdist, pool)
+    call = (pool[0], "rgb")
+    if args.host_inputs:
+        pool = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in pool]
+    return run(args, model, call, model, rank, world, device, dist, mdist, pool)
 
 
 def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
@@ -487,7 +494,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
         from madm_amd.pipeline import StagedExtractor
         # A/B switches for the cost of the product API's per-submit work: MADM_EXP_NO_SYNC_INPUTS=1
         # drops the caller-stream event, MADM_EXP_NO_RANGE=1 the deferred range check
-        runner = pipe = StagedExtractor(ldm, pool[0], unet_streams=args.pipeline, slots=args.slots or None,
+        runner = pipe = StagedExtractor(ldm, call[0], unet_streams=args.pipeline, slots=args.slots or None,
                                         sync_inputs=not int(os.environ.get("MADM_EXP_NO_SYNC_INPUTS", "0")),
                                         range_check=False if int(os.environ.get("MADM_EXP_NO_RANGE", "0")) else None)
 
@@ -570,7 +577,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
                          device=device)
             m2(*call)
             torch.cuda.synchronize()
-            pipe2 = StagedExtractor(m2, pool[0], unet_streams=args.pipeline, streams=pipe.streams, slots=args.slots or None)
+            pipe2 = StagedExtractor(m2, call[0], unet_streams=args.pipeline, streams=pipe.streams, slots=args.slots or None)
             for i in range(args.warmup):
                 pipe2.submit(pool[i % len(pool)])
             torch.cuda.synchronize()
@@ -596,7 +603,9 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
         # projections) + the head on the 512 x 1024 canvas (2 x 1 821.27)
         alg = {"extract": ALG_FLOP_PER_IMAGE, "eval": 6.34725e12,
                "slide": 3 * (1.91993e12 + 2.51452e12 + 0.09153e12) + 2 * 1.82127e12}[args.workload]
-        fed = (f"every step submits a different seeded batch (pool of {len(pool)}, resident in HBM) through "
+        fed = (f"every step submits a different seeded batch (pool of {len(pool)}, "
+               + ("in PINNED HOST memory: PCIe-inclusive, informational" if getattr(args, "host_inputs", False) else "resident in HBM")
+               + ") through "
                "{}.submit(batched_inputs): the inputs are copied into the slot's static buffers on the device per step")
         if args.no_graph:
             launch = "eager launches, a different seeded batch per step"

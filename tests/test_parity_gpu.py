@@ -207,6 +207,15 @@ def test_staged_pipeline_matches_forward(extractor, slots):
             got.append([f.clone() for f in outs])
         pipe.drain()
         assert pipe.range_check.checked == len(batches)
+        if slots is None:
+            # the same batches from HOST memory (pinned image, pageable prompt tokens): copied in on the pipeline's transfer stream
+            for b in batches:
+                hb = {"img": b["img"].cpu().pin_memory(), "cond_inputs": b["cond_inputs"].cpu(), "cond_emb": b["cond_emb"]}
+                outs, done = pipe.submit(hb)
+                done.synchronize()
+                got.append([f.clone() for f in outs])
+            pipe.drain()
+            want = want + want
     _assert_slots_equal(got, want)
 
 
