@@ -171,6 +171,9 @@ int madm_conv2d_pick_tile(const madm_conv2d_args* a);
 /* tuning/debug aid: force the workgroup tile (0 = tuned table then heuristic, -1 = heuristic only,
  * 1..11 = the tile codes of madm_conv2d_pick_tile). */
 void madm_debug_set_conv_tile(int tile);
+/* test aid: fills the LDS of every CU with `pattern` (0x7fc00000 = quiet NaN) -- a kernel that reads LDS it has not written then
+ * fails deterministically instead of depending on its predecessor on the CU.  sink: 4 bytes of device memory, never written. */
+int madm_debug_poison_lds(unsigned pattern, void* sink, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * GroupNorm (32 groups in SD-v1-4; any G dividing Ctot), channels-last.  The normalised tensor has

@@ -113,6 +113,7 @@ SYMBOLS = [
                                         c_float, c_void_p, c_void_p, c_void_p]),
     ("madm_conv2d_fwd", c_int, [ctypes.POINTER(Conv2dArgs), c_void_p]),
     ("madm_debug_set_conv_tile", None, [c_int]),
+    ("madm_debug_poison_lds", c_int, [ctypes.c_uint, c_void_p, c_void_p]),
     ("madm_groupnorm_stats", c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     ("madm_groupnorm_apply", c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_int,
@@ -221,6 +222,36 @@ def _load():
 
 
 lib = _load()
+
+
+class _PoisonedLib:
+    """Debug harness (MADM_DEBUG_POISON_LDS=1; tests/test_ops_gpu.py::test_suite_under_lds_poison drives it): every launch
+    through the C ABI is preceded, on the same stream, by madm_debug_poison_lds -- all LDS of the chip holds quiet NaNs when
+    the kernel starts.  A kernel that reads LDS it did not write then fails its parity test deterministically; without the
+    harness such a read returns whatever the previous kernel on that CU left there (a dependence on history)."""
+
+    def __init__(self, raw):
+        object.__setattr__(self, "_raw", raw)
+        object.__setattr__(self, "_sink", None)
+        object.__setattr__(self, "_launching", {n for n, _r, a in SYMBOLS if a and a[-1] is c_void_p and n.startswith("madm_")
+                                                and not n.startswith("madm_debug")})
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+        if name not in self._launching:
+            return fn
+
+        def call(*args):
+            import torch
+            if self._sink is None:
+                object.__setattr__(self, "_sink", torch.zeros(1, dtype=torch.int32, device="cuda"))
+            self._raw.madm_debug_poison_lds(0x7fc00000, self._sink.data_ptr(), args[-1])
+            return fn(*args)
+        return call
+
+
+if int(os.environ.get("MADM_DEBUG_POISON_LDS", "0")):
+    lib = _PoisonedLib(lib)
 
 
 def check(rc, what):

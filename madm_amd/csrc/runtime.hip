@@ -52,9 +52,29 @@ __global__ __launch_bounds__(256) void calib_mfma_loop_kernel(int iters, float* 
     if (s == 12345.678f) sink[0] = s;
 #endif
 }
+// Test infrastructure (tools/exp/stress_eval_f32.py, tests/test_ops_gpu.py::test_kernels_do_not_read_unwritten_lds): every CU's
+// LDS filled with a pattern (quiet NaNs by default) by workgroups that each take 80 KB (two per CU = all 160 KB).  A kernel that reads LDS it has not
+// written then computes garbage DETERMINISTICALLY instead of depending on what ran on the CU before it.
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned pattern, unsigned* sink) {
+    extern __shared__ unsigned poison_smem[];
+    for (int i = threadIdx.x; i < 20480; i += 256) poison_smem[i] = pattern;
+    __syncthreads();
+    // keep the stores alive; hold the CU for a moment so that the grid spreads over all CUs
+    unsigned acc = 0;
+    for (int r = 0; r < 64; ++r) acc += poison_smem[(threadIdx.x * 61 + r * 257) % 20480];
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 }  // namespace
 
 extern "C" {
+int madm_debug_poison_lds(unsigned pattern, void* sink, void* stream) {
+    MADM_REQUIRE(sink != nullptr, "poison_lds: a 4-byte device sink");
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = madm_raise_dynamic_lds(reinterpret_cast<const void*>(poison_lds_kernel), (size_t)81920, attr_done, "poison_lds")) return e;
+    poison_lds_kernel<<<dim3(2048), 256, 81920, (hipStream_t)stream>>>(pattern, (unsigned*)sink);
+    return madm_check_launch("poison_lds_kernel");
+}
+
 int madm_abi_version(void) { return MADM_ABI_VERSION; }
 const char* madm_last_error(void) { return g_err; }
 

@@ -317,6 +317,17 @@ def conv2d_wgrad(x1, dout, B, IH, IW, *, x2=None, KH=1, KW=1, stride=1, pad_t=0,
     return dw
 
 
+_poison_sink = {}
+
+
+def poison_lds(device, pattern=0x7fc00000):
+    """Test aid (madm_debug_poison_lds): every CU's LDS filled with ``pattern`` (default: quiet NaNs) on the current stream."""
+    sink = _poison_sink.get(str(device))
+    if sink is None:
+        sink = _poison_sink[str(device)] = torch.zeros(1, dtype=torch.int32, device=device)
+    check(lib.madm_debug_poison_lds(int(pattern), sink.data_ptr(), _stream()), "madm_debug_poison_lds")
+
+
 def pack_weight(w, dtype, ktile, splits=None, interleave=False):
     """f32 master weight on the GPU ([N, Cin, KH, KW] conv or [N, K] linear) -> the packed forward operand
     [N, KH*KW*sum(pad(splits))] of ``dtype`` in one launch (packing.pack_conv_weight / pack_linear_weight / the row
