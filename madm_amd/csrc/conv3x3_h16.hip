@@ -133,6 +133,33 @@ __device__ __forceinline__ void h16_epilogue(const IgemmP& p, f32x4 (&acc)[MI][B
     }
 }
 
+// split-K slices: the f32 partial tile goes to the workspace slab of slice z, nothing else (bias, residual, statistics belong
+// to the reduction).  A kernel instantiation of its own (SK): inside h16_epilogue the store loop shares its registers with the
+// full epilogue's live ranges and the compiler spilled 600 .. 900 VGPRs around it (467 scratch instructions per wave).
+template <int BN, int MI>
+__device__ __forceinline__ void h16_epilogue_splitk(const IgemmP& p, const f32x4 (&acc)[MI][BN / 32], int b, int py0, int px0, int n0,
+                                                    int z) {
+    constexpr int NI = BN / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int nb = n0 + wn * (BN / 2) + fg * 4;
+    const int ox = px0 + frow;
+    float* const slab = p.ws + (size_t)z * p.M * p.N + nb;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int oy = py0 + wm * MI + i;
+        if (oy < p.OH && ox < p.OW) {
+            float* row = slab + (size_t)((b * p.OH + oy) * p.OW + ox) * p.N;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const f32x4 v = acc[i][j];
+                if (nb + 16 * j < p.N) *reinterpret_cast<float4*>(row + 16 * j) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
 // The same for 16-bit outputs without split-K / GEGLU: the finished values (bias, time row, residual, ReLU applied in
 // registers as above) are rounded to T, written to an LDS tile [256 pixels][BN channels] (rows padded by 16 B) and leave as
 // 16-byte stores, 16 lanes per pixel row = full 256-byte lines -- the direct path stores 8-byte pieces of 16 different rows
@@ -271,7 +298,7 @@ __device__ __forceinline__ void h16_epilogue_lds(const IgemmP& p, f32x4 (&acc)[M
     H16_STAMP(2005);
 }
 
-template <typename T, int BN, bool FUSE, bool WIDE>
+template <typename T, int BN, bool FUSE, bool WIDE, bool SK>
 __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
     kernarg_touch<5>();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -553,7 +580,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, int
     // the epilogue is VALU work on the block's critical path like the GroupNorm pass: raised issue priority beside the partner
     // workgroup's MFMA stream (same box, two runs each: 361.0 / 361.8 -> 363.1 / 362.9 images/s; priority 1: 360.3 / 361.1)
     __builtin_amdgcn_s_setprio(3);
-    if constexpr (WIDE) h16_epilogue_lds<T, BN, MI>(p, acc, b, py0, px0, n0, smem_raw, lds0);
+    if constexpr (SK) h16_epilogue_splitk<BN, MI>(p, acc, b, py0, px0, n0, z);
+    else if constexpr (WIDE) h16_epilogue_lds<T, BN, MI>(p, acc, b, py0, px0, n0, smem_raw, lds0);
     else h16_epilogue<T, BN, MI>(p, acc, b, py0, px0, n0, z, reinterpret_cast<float*>(smem_raw));
     H16_STAMP(5);
 #endif
@@ -569,7 +597,7 @@ extern "C" int madm_debug_read_h16_stamps(unsigned long long* host, int n) {
 
 namespace {
 
-template <typename T, int BN, bool FUSE, bool WIDE>
+template <typename T, int BN, bool FUSE, bool WIDE, bool SK = false>
 int launch_h16_one(const IgemmP& p0, hipStream_t s) {
     IgemmP p = p0;
     constexpr size_t lds0 = (size_t)((H16_PIX + 7) / 8) * 1024 + 2 * (size_t)BN * 128 + 32 * sizeof(float2);
@@ -577,7 +605,7 @@ int launch_h16_one(const IgemmP& p0, hipStream_t s) {
     // rest of the CU stays free for the workgroups of kernels on other streams (staged pipeline)
     static const size_t lds_exp = [] { const char* e = getenv("MADM_EXP_H16_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
     const size_t lds = lds_exp > lds0 ? lds_exp : lds0;
-    auto kern = conv3x3_h16_kernel<T, BN, FUSE, WIDE>;
+    auto kern = conv3x3_h16_kernel<T, BN, FUSE, WIDE, SK>;
     // the attribute is per device: one bit per device id, set once (atomic: host threads may launch concurrently)
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
@@ -610,6 +638,7 @@ int launch_conv3x3_h16(const IgemmP& p, int bn, hipStream_t s) {
         return MADM_ERR_UNSUPPORTED;
     }
     (void)bn;
+    if (p.splitk > 1) return fuse ? launch_h16_one<T, 128, true, false, true>(p, s) : launch_h16_one<T, 128, false, false, true>(p, s);
     if constexpr (sizeof(T) == 2) {
         if (p.splitk == 1 && !p.out_f32 && p.epilogue != MADM_EPI_GEGLU && (p.ldo & 7) == 0 && (p.N & 7) == 0)
             return fuse ? launch_h16_one<T, 128, true, true>(p, s) : launch_h16_one<T, 128, false, true>(p, s);

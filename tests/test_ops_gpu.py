@@ -90,6 +90,9 @@ CONV_CASES = [
     # 12 = 16 x 16-patch halo conv with the nearest-2x upsample folded into its halo gather (Upsample2D), full / ragged
     ("h16_upsample", 2, [64], 16, 16, 128, 3, 1, "same", True, 12, 1),
     ("h16_upsample_ragged_concat", 1, [128, 64], 9, 13, 192, 3, 1, "same", True, 12, 1),
+    # split-K slices of the 16 x 16-patch kernel (its own lean epilogue instantiation): K = 9 x 192 in 3 slices, ragged patches, N = 192
+    ("h16_splitk3_ragged", 2, [128, 64], 19, 35, 192, 3, 1, "same", False, 12, 3),
+    ("h16_splitk2_upsample", 1, [128], 16, 16, 128, 3, 1, "same", True, 12, 2),
 ]
 
 
