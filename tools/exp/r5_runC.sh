@@ -1,12 +1,10 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5s; mkdir -p $O
+# side-by-side re-tune of the 3x3 conv classes after the lean split-K epilogue of the 16x16 kernel
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5u; mkdir -p $O
 cd $R
-python -m pytest tests/test_ops_gpu.py -x -q -k "h16 or conv2d" > $O/pytest_h16.log 2>&1; echo "pytest h16 rc=$?"; tail -3 $O/pytest_h16.log
-python -m pytest tests/test_parity_gpu.py -x -q -k "golden and full_t0" > $O/pytest_gold.log 2>&1; echo "pytest golden rc=$?"; tail -3 $O/pytest_gold.log
+python tools/tune_concurrent.py --max-m 100000000 --min-us 15 --only " k3 " --rows $O/tuned_side.txt > $O/tune_concurrent.txt 2>&1; tail -40 $O/tune_concurrent.txt
 B="--no-cpu-baseline --no-kernel-profile --no-alt-dtype --no-calib --steps 50 --warmup 10"
-for rep in 1 2 3; do
-  python bench.py $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('lean split-K epilogue', d['value'], d['ms_per_step'], d['serial_ms_per_step'])"
-done | tee $O/bench3.txt
-for rep in 1 2 3; do
-  MADM_HIP_LIB=$R/build/libmadm_hip_before_sk.so python bench.py $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('before               ', d['value'], d['ms_per_step'], d['serial_ms_per_step'])"
-done | tee -a $O/bench3.txt
+for rep in 1 2; do
+python bench.py $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('table   ', d['value'], d['ms_per_step'], d['serial_ms_per_step'])"
+MADM_TUNED_FILE=$O/tuned_side.txt python bench.py $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('new rows', d['value'], d['ms_per_step'], d['serial_ms_per_step'])"
+done | tee $O/ab_rows.txt
