@@ -102,6 +102,13 @@ def _zeros(n, dev):
     return _const_cache[key]
 
 
+def _const_timesteps(t, n, dev):
+    key = ("ts", int(t), n, str(dev))
+    if key not in _const_cache:
+        _const_cache[key] = torch.full((n,), int(t), dtype=torch.int64, device=dev)
+    return _const_cache[key]
+
+
 def _zeros_i64(n, dev):
     key = ("zi", n, str(dev))
     if key not in _const_cache:
@@ -404,7 +411,10 @@ class LdmRocm(nn.Module):
             low_timestep, high_timestep = batched_inputs['timestep'][0], batched_inputs['timestep'][1]
         else:
             low_timestep, high_timestep = 0, 1
-        timesteps = torch.randint(low=low_timestep, high=high_timestep, size=(B,), device=dev).long()
+        if high_timestep - low_timestep == 1:   # a one-value range (every shipped config): no draw, no RNG kernel in the graph
+            timesteps = _const_timesteps(low_timestep, B, dev)
+        else:
+            timesteps = torch.randint(low=low_timestep, high=high_timestep, size=(B,), device=dev).long()
         h, w = moments.H, moments.W
         noise = _sized_noise(self.shared_noise, (h, w))
         sa, sn = self.noise_scheduler.tables(dev)
