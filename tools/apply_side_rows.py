@@ -27,7 +27,7 @@ def main():
         tile, sk = int(m.group(7)), int(m.group(8))
         s0, s1, a0, a1 = (float(m.group(i)) for i in range(9, 13))
         if s1 + w * a1 < 0.97 * (s0 + w * a0):
-            new[key] = (tile, sk, f"r4 side-by-side: side {s0:.1f} -> {s1:.1f} us, alone {a0:.1f} -> {a1:.1f}")
+            new[key] = (tile, sk, f"r5 side-by-side: side {s0:.1f} -> {s1:.1f} us, alone {a0:.1f} -> {a1:.1f}")
         else:
             print("rejected", key, tile, sk, f"side {s0} -> {s1}, alone {a0} -> {a1}")
     lines = open(INC).read().split("\n")
@@ -47,7 +47,7 @@ def main():
     if extra:
         while out and out[-1] == "":
             out.pop()
-        out.append("// -- round 4: shapes without a row so far (tools/tune_concurrent.py; variant 3 = stride 2)")
+        out.append("// -- round 5: shapes without a row so far (tools/tune_concurrent.py; variant 3 = stride 2)")
         for k in sorted(extra):
             t, sk, why = new[k]
             out.append("{%d, %d, %d, %d, %d, %d, %d, %d},   // %s" % (*k, t, sk, why))

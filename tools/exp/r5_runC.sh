@@ -1,9 +1,10 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5z; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5B; mkdir -p $O
 cd $R
-python -m pytest tests/test_parity_gpu.py tests/test_eval_gpu.py -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.log
-B="--no-cpu-baseline --no-kernel-profile --no-alt-dtype --no-calib --steps 50 --warmup 10"
-for rep in 1 2 3; do
-python bench.py $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('new table', d['value'], d['ms_per_step'], d['serial_ms_per_step'])"
-done | tee $O/bench3.txt
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('driver flags', d['value'], d['ms_per_step'], d['serial_ms_per_step'], d['roofline']['frac'], d['calib']['h16_128x128_512sq_us'], d['alt_dtype'])" | tee -a $O/bench3.txt
+python -m pytest tests/test_eval_gpu.py -x -q > $O/pytest_eval.log 2>&1; echo "pytest eval rc=$?"; tail -2 $O/pytest_eval.log
+python bench.py --workload eval --steps 20 --warmup 4 --no-kernel-profile 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('eval, new table', d['value'], d['ms_per_step'], d['serial_ms_per_step'])"
+python tools/tune_concurrent.py --workload slide --max-m 100000000 --min-us 30 --rows $O/tuned_side_slide.txt > $O/tune_concurrent_slide.txt 2>&1; grep -E "^1 |sums over" $O/tune_concurrent_slide.txt | head -50
+for rep in 1 2; do
+python bench.py --workload slide --steps 10 --warmup 3 --no-kernel-profile 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('slide table   ', d['value'], d['ms_per_step'], d['serial_ms_per_step'])"
+MADM_TUNED_FILE=$O/tuned_side_slide.txt python bench.py --workload slide --steps 10 --warmup 3 --no-kernel-profile 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('slide new rows', d['value'], d['ms_per_step'], d['serial_ms_per_step'])"
+done | tee $O/ab_rows_slide.txt

@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--max-m", type=int, default=8192, help="largest M tuned (the VAE's 512^2 .. 128^2 maps lie above)")
     ap.add_argument("--rows", default="", help="write MADM_TUNED_FILE rows of the side-by-side winners here")
     ap.add_argument("--only", default="", help="regex on the shape description")
-    ap.add_argument("--workload", default="extract", choices=["extract", "eval", "train"],
+    ap.add_argument("--workload", default="extract", choices=["extract", "eval", "slide", "train"],
                     help="train: the launches of one optimisation step (forward + data gradients; eager, one stream: use --streams 1); "
                          "rows are written only for shapes the table does not hold yet")
     args = ap.parse_args()
@@ -143,6 +143,10 @@ def main():
         args.batch = 1
         m = bench.build_eval_model(dtype, torch.device("cuda"))
         call = ([{"target_second_modality": 255.0 * torch.rand((3, 512, 512)).cuda()}],)
+    elif args.workload == "slide":   # configs[4] geometry: 512 x 1024 image, three 512-wide windows batched as B = 3 (square maps only:
+        args.batch = 3               # the head's 512 x 1024 canvas is skipped by the Layer constructor)
+        m = bench.build_eval_model(dtype, torch.device("cuda"), slide=True, num_classes=9)
+        call = ([{"target_second_modality": 255.0 * torch.rand((3, 512, 1024)).cuda()}],)
     elif args.workload == "train":   # BASELINE configs[3]: one MadmTrainer step (its conv2d launches incl. the data gradients)
         from madm_amd.train import MadmTrainer
         torch.set_grad_enabled(True)
