@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--max-m", type=int, default=8192, help="largest M tuned (the VAE's 512^2 .. 128^2 maps lie above)")
     ap.add_argument("--rows", default="", help="write MADM_TUNED_FILE rows of the side-by-side winners here")
     ap.add_argument("--only", default="", help="regex on the shape description")
+    ap.add_argument("--lora", action="store_true", help="extract workload with one r = 8 adapter active (bench.py --lora): the "
+                    "K-extended projection GEMMs and the skinny x A^T GEMMs get rows of their own")
     ap.add_argument("--workload", default="extract", choices=["extract", "eval", "slide", "train"],
                     help="train: the launches of one optimisation step (forward + data gradients; eager, one stream: use --streams 1); "
                          "rows are written only for shapes the table does not hold yet")
@@ -159,6 +161,12 @@ def main():
         m = LdmRocm("", [], [5, 8, 11], [], input_range='-1+1', unet_block_indices_type='after', finetune_unet='no',
                     compute_dtype=dtype, weights='synthetic', seed=0)
         call = (bench.make_inputs(args.batch, 512, torch.device("cuda")), "rgb")
+        if args.lora:
+            from types import SimpleNamespace
+            from madm_amd import weights
+            m.unet.add_adapter(SimpleNamespace(r=8, lora_alpha=8, target_modules=["to_k", "to_q", "to_v", "to_out.0"]), "Depth")
+            m.unet.set_adapter(["Depth"])
+            weights.randomize_lora_B_(m.unet)
     m(*call)
     torch.cuda.synchronize()
     ops.PROFILE = []
