@@ -65,10 +65,11 @@ def parse():
     ap.add_argument("--graphs", type=int, default=1,
                     help="graph executables replayed round-robin (measured: 1, 2 and 3 give the same step time, the "
                          "host-side launch of a replay already overlaps the previous one)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="whole-forward mode (eval / slide workloads, or --pipeline 0): HIP streams the graph executables are "
-                         "replayed on, round-robin, so consecutive steps overlap (measured eval: 71.6 / 86.6 / 92.9 images/s on "
-                         "1 / 2 / 3 streams; four hardware pipes serve the queues, a fourth stream loses again)")
+                         "replayed on, round-robin, so consecutive steps overlap.  Four hardware pipes serve the queues: one stream "
+                         "per pipe (round 5, same box, eval images/s on 2 / 3 / 4 / 5 / 6 / 8 streams: 103.7 / 111.6 / 116.8 / 97.7 / "
+                         "103.9 / 104.2; sliding windows 3 / 4 / 5: 45.3 / 46.7 / 44.6; profiles/round5_ab_eval_streams.txt)")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="extract workload: UNet streams of the staged pipeline (madm_amd/pipeline.py: every batch's VAE "
                          "encoder on one stream, its UNet on one of K streams, so K UNets of consecutive batches run side by "

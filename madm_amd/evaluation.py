@@ -70,7 +70,7 @@ class SemSegEvaluator:
         return {"sem_seg": res}
 
 
-def inference_on_dataset(model, data_loader, evaluator, streams=3, range_check=None):
+def inference_on_dataset(model, data_loader, evaluator, streams=4, range_check=None):
     """``inference_on_dataset`` of /root/reference/evaluation/evaluator.py:30-139 (the loop at :75-93) on the throughput
     launch path: every ``inputs`` of the loader goes through ``pipeline.GraphedInference.submit`` (whole-forward hipGraphs,
     ``streams`` images in flight) and ``evaluator.process`` is enqueued on the slot's stream right behind the forward --

@@ -13,7 +13,8 @@ by side and the next encoder slides under them.  Each in-flight batch owns a SLO
 (latents, timesteps) and its own output tensors; a slot's copies and encoder wait until the slot's previous UNet has finished.
 
 ``GraphedInference`` -- the whole ``MadmInference.forward`` (pad -> prompt -> extractor -> VAE decoder -> projections ->
-DAFormer head -> resize) as one graph per slot, slots round-robin on ``streams`` streams, same submit contract.
+DAFormer head -> resize) as one graph per slot, slots round-robin on ``streams`` streams (default 4: one per hardware pipe of
+the queue scheduler; a fifth stream shares a pipe and loses 15 %), same submit contract.
 
 The reference's per-call input-range assert (ldm_diffusers.py:147: ``assert -1 <= images.min() and images.max() <= 1``, a host
 sync per call) is kept as a DEFERRED check: the stem kernel's min / max probe of every submitted batch is copied to a pinned
@@ -309,7 +310,7 @@ class GraphedInference:
     returns (``[{'sem_seg': [1,K,H,W]}]``, event).  One image size per runner (the graphs are captured for it); the
     extractor's range assert is deferred as in ``StagedExtractor``."""
 
-    def __init__(self, model, example_inputs, streams=3, slots=None, sync_inputs=True, range_check=None):
+    def __init__(self, model, example_inputs, streams=4, slots=None, sync_inputs=True, range_check=None):
         self.model = model
         self.n_streams = int(streams)
         self.n_slots = int(slots or streams)

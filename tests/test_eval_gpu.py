@@ -296,7 +296,7 @@ def test_device_evaluator_is_bit_exact(cuda):
 
 
 def test_inference_on_dataset_pipelined_matches_serial_loop(cuda):
-    """evaluation.inference_on_dataset (the reference's loop, evaluator.py:75-93, on whole-forward hipGraphs with three images
+    """evaluation.inference_on_dataset (the reference's loop, evaluator.py:75-93, on whole-forward hipGraphs with four images
     in flight and evaluator.process chained on the slot's stream): eight DIFFERENT images of two sizes -> every sem_seg
     bit-identical to MadmInference.forward on that image, the confusion matrix and the metrics equal to the serial loop's;
     an out-of-range image (values > 255) raises the reference's range assert, late."""
@@ -324,7 +324,7 @@ def test_inference_on_dataset_pipelined_matches_serial_loop(cuda):
             super().process(inputs, outputs)
 
     ev = Recording(K, ignore_label=255)
-    res = inference_on_dataset(model, loader, ev, streams=3)
+    res = inference_on_dataset(model, loader, ev)
     ev2 = SemSegEvaluator(K, ignore_label=255)
     for i, inputs in enumerate(loader):
         out = model(inputs)
