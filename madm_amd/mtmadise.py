@@ -20,6 +20,7 @@ NotImplementedError.  ``reg_uncertain`` only feeds the reference's visualisation
 accepted and changes nothing but the teacher call's ``return_unet_final_output`` (which the VAE-decoder branch computes
 anyway).  The periodic matplotlib dump (``vis_results``) is out of scope.
 """
+import os
 import random
 from copy import deepcopy
 
@@ -57,6 +58,8 @@ class MTMADISE(MadmInference):
         self.criterion = criterion
         self.train_iter_index = 0
         self.ema_alpha, self.pseudo_threshold = ema_alpha, pseudo_threshold
+        self.overlap_teacher = not bool(int(os.environ.get("MADM_NO_TEACHER_OVERLAP", "0")))
+        self._teacher_stream, self._teacher_warm = None, False
         self.blur, self.color_jitter_strength, self.color_jitter_probability = blur, color_jitter_strength, color_jitter_probability
         self.enable_mixup, self.pl_crop, self.color_aug_flag = enable_mixup, pl_crop, color_aug_flag
         self.color_aug = color_aug        # callable(strong_parameters, data [N,3,H,W]) -> data; None: augment.strong_color
@@ -204,6 +207,39 @@ class MTMADISE(MadmInference):
         K = self.sem_seg_head.num_classes
         ctxs = {}
 
+        # ---- teacher: pseudo labels ----
+        # The EMA teacher's forward reads nothing the student passes write (its own UNet / head copies, the frozen VAE) and its
+        # result is needed only where the labels are mixed: it runs on a side stream beside the two student forwards (from the
+        # second step on: the first builds the shared packed operands of the frozen modules in one stream).  Same kernels,
+        # same values; the Python-side random draws keep their order (random: two uniforms above, this randint; numpy: the
+        # class choices below).  MADM_NO_TEACHER_OVERLAP=1 for A/B runs.
+        main_stream = torch.cuda.current_stream(source.device)
+        overlap = self.overlap_teacher and self._teacher_warm
+        side = main_stream
+        if overlap:
+            if self._teacher_stream is None:
+                self._teacher_stream = torch.cuda.Stream(device=source.device)
+            side = self._teacher_stream
+            side.wait_stream(main_stream)                 # inputs, and this step's EMA update, are in front of it
+        with torch.no_grad(), torch.cuda.stream(side):
+            self.set_lora_adapter(state=tmod)
+            kw = dict(input_modal='others', ema_forward=True)
+            if self.rev_noise_sup and self.train_iter_index <= self.rev_noise_end_iter:
+                t_ = random.randint(self.denoise_timestep_range[0], self.denoise_timestep_range[1])
+                if self.rev_noise_gradually:
+                    t_ = int(t_ * (1 - self.train_iter_index / self.rev_noise_end_iter))
+                kw['timestep'] = (t_, t_ + 1)
+            if self.reg_uncertain:
+                low_res_feats, _ = self.backbone(target, return_unet_final_output=True, **kw)
+            else:
+                low_res_feats = self.backbone(target, **kw)
+            head_t = self.ema_sem_seg_head
+            ema_logits = head_t.forward_tokens([low_res_feats['output_features'].tok[k] for k in head_t.in_keys])
+            ema_nchw = ops.nhwc_to_nchw(ema_logits.t, B, K, ema_logits.H, ema_logits.W)
+            pseudo_prob, pseudo_label, pseudo_weight = L.pseudo_labels(ema_nchw, target.shape[2:], self.pseudo_threshold)
+            del low_res_feats, ema_logits
+        self._teacher_warm = True
+
         # ---- source pass ('default' adapter, input_modal 'rgb') ----
         self.set_lora_adapter(state='default')
         source_logits, source_out, rec_s = self._student_pass(source, 'rgb')
@@ -226,23 +262,12 @@ class MTMADISE(MadmInference):
         self.set_lora_adapter(state=tmod)
         target_logits, target_out, rec_t = self._student_pass(mixed_img, 'mixed')
 
-        # ---- teacher: pseudo labels ----
+        # ---- label / weight mixing with the teacher's pseudo labels ----
+        if overlap:
+            main_stream.wait_stream(side)
+            for t_side in (ema_nchw, pseudo_prob, pseudo_label, pseudo_weight):
+                t_side.record_stream(main_stream)
         with torch.no_grad():
-            self.set_lora_adapter(state=tmod)
-            kw = dict(input_modal='others', ema_forward=True)
-            if self.rev_noise_sup and self.train_iter_index <= self.rev_noise_end_iter:
-                t_ = random.randint(self.denoise_timestep_range[0], self.denoise_timestep_range[1])
-                if self.rev_noise_gradually:
-                    t_ = int(t_ * (1 - self.train_iter_index / self.rev_noise_end_iter))
-                kw['timestep'] = (t_, t_ + 1)
-            if self.reg_uncertain:
-                low_res_feats, _ = self.backbone(target, return_unet_final_output=True, **kw)
-            else:
-                low_res_feats = self.backbone(target, **kw)
-            head_t = self.ema_sem_seg_head
-            ema_logits = head_t.forward_tokens([low_res_feats['output_features'].tok[k] for k in head_t.in_keys])
-            ema_nchw = ops.nhwc_to_nchw(ema_logits.t, B, K, ema_logits.H, ema_logits.W)
-            pseudo_prob, pseudo_label, pseudo_weight = L.pseudo_labels(ema_nchw, target.shape[2:], self.pseudo_threshold)
             if self.pl_crop:
                 pseudo_weight[:, :self.psweight_ignore_top, :] = 0
             if self.enable_mixup:

@@ -25,6 +25,10 @@ class MadmTrainer:
                  amp=True, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
                  lr_multiplier=None, exchange="allreduce", wire_dtype=None):
         self.model = model
+        try:      # the extractor whose per-pass range assert this trainer defers to the end of its step
+            self._ldm = model.backbone.feature_extractor.ldm_extractor
+        except AttributeError:
+            self._ldm = None
         table = optim.default_optimizer_params(model, lr, weight_decay, weight_decay_norm=0.0, weight_decay_bias=0.0,
                                                unet_lr=unet_lr)
         assert table, "nothing to train"
@@ -134,7 +138,15 @@ class MadmTrainer:
         self._final = [False] * len(self._final)
         self._ptr = len(self._final) - 1
         self.reduced_during_backward = 0
-        loss_dict = model(data)
+        ldm = self._ldm
+        if ldm is not None and ldm.check_input_range:
+            ldm.deferred_range_probes = []        # the three passes' range asserts (ldm_diffusers.py:147): checked at the step's end
+        try:
+            loss_dict = model(data)
+        finally:
+            probes = [] if ldm is None else (ldm.deferred_range_probes or [])
+            if ldm is not None:
+                ldm.deferred_range_probes = None
         losses = sum(loss_dict.values())
         (losses * self.scale).backward()
         self.flush()
@@ -163,7 +175,11 @@ class MadmTrainer:
             ev[1].synchronize()
             self.last_allreduce_exposed_ms = ev[0].elapsed_time(ev[1])
             self.last_overlap_frac = self.reduced_during_backward / max(1, self.opt.flat.numel)
-        return {k: float(v.detach()) for k, v in loss_dict.items()}, norm, stepped
+        out = {k: float(v.detach()) for k, v in loss_dict.items()}       # (the step's host sync)
+        for i, mm in enumerate(probes):
+            lo, hi = mm.tolist()
+            assert -1 <= lo and hi <= 1, f"input range check (ldm_diffusers.py:147), forward pass {i} of this step: min {lo} max {hi}"
+        return out, norm, stepped
 
 
 class ExtractorTrainer:
