@@ -3,9 +3,11 @@
 
 One "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
 VAE encode -> add_noise -> UNet (LoRA off, shipped configs) -> taps [1280@16, 640@32, 320@64] handed
-over as NCHW f32, i.e. LdmRocm.forward (== LdmDiffusers.forward, ldm_diffusers.py:143-217).  The
-forward is captured once into a hipGraph (torch.cuda.CUDAGraph around the C-ABI launches) and
-replayed; timing brackets exactly K replays with barrier + synchronize, max over ranks.
+over as NCHW f32, i.e. LdmRocm.forward (== LdmDiffusers.forward, ldm_diffusers.py:143-217).  Every
+step goes through the product runner (madm_amd/pipeline.py::StagedExtractor.submit with a DIFFERENT
+seeded batch: hipGraph executables of the two stages on four streams, the reference's input-range
+assert kept as a deferred check); timing brackets exactly K submits with barrier + synchronize,
+max over ranks.
 
 Multi-GPU: the path shards by image with no exchange step ("replicas only"): every
 rank runs its own bs=2 batch; RCCL is used only for the barrier and the max-over-ranks of the time.
