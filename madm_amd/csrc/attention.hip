@@ -460,7 +460,9 @@ extern "C" int madm_debug_read_attn_stamps(unsigned long long* host, int n) {
 }
 #endif
 
-static const bool g_attn_nw8 = [] { const char* e = getenv("MADM_ATTN_NW8"); return e && atoi(e) != 0; }();
+// d = 40 at >= 2048 queries: eight-wave workgroups (two query groups per wave) -- round 5, six-slot pipeline, same box, two runs:
+// 372.8 / 373.1 -> 375.3 / 374.7 images/s, serial 8.05 -> 8.01 ms (equal in round 4's pipeline).  MADM_ATTN_NW8=0 for the four-wave form.
+static const bool g_attn_nw8 = [] { const char* e = getenv("MADM_ATTN_NW8"); return !(e && atoi(e) == 0); }();
 static const bool g_attn_nq1 = [] { const char* e = getenv("MADM_ATTN_NQ1"); return e && atoi(e) != 0; }();   // A/B switch
 
 extern "C" int madm_attention_fwd(const madm_attention_args* a, void* stream) {
