@@ -159,8 +159,11 @@ class StagedExtractor:
             self.s_enc = masked(e0, e1)
             self.s_unet = [masked(u0, u1) for _ in range(self.k)]
         else:
-            # experiment switch MADM_EXP_PRIO: "u" = UNet streams high priority, "e" = encoder stream high priority
-            prio = os.environ.get("MADM_EXP_PRIO", "")
+            # the encoder stream at high priority: its chip-filling kernels are the pipeline's pacemaker, and with six slots the
+            # UNet streams always have work queued behind them (round 5, same box, two runs: 372.6 / 372.2 -> 377.6 / 377.7
+            # images/s; UNet streams high instead: 370.2 / 369.6; round 3's three-slot pipeline: 307.9 vs 311.6 without).
+            # MADM_EXP_PRIO: "e" (default) / "u" = UNet streams high / "0" = all equal
+            prio = os.environ.get("MADM_EXP_PRIO", "e")
             self.s_enc = torch.cuda.Stream(device=dev, priority=-1 if prio == "e" else 0)
             self.s_unet = [torch.cuda.Stream(device=dev, priority=-1 if prio == "u" else 0) for _ in range(self.k)]
         # per-slot static inputs: the graphs read THESE tensors; everything that is not a tensor is a capture-time constant
