@@ -334,3 +334,28 @@ def test_lora_targets_outside_the_attention_projections_are_refused():
     sd_unet.UNet2DConditionModel.add_adapter(t, SimpleNamespace(r=4, lora_alpha=4, target_modules=["to_k", "to_q", "to_v", "to_out.0"]), "x")
     wrapped = [n for n, m in t.named_modules() if isinstance(m, sd_unet.LoraLinear)]
     assert len(wrapped) == 8 and type(t.transformer_blocks[0].ff.net[2]) is sd_unet.Linear
+
+
+def test_tuned_table_rows_are_valid_and_unique():
+    """madm_amd/csrc/igemm_tuned.inc (tile / split-K rows chosen by tools/tune_concurrent.py): every row names an existing tile code
+    and a split-K >= 1, no (dtype, M, N, K, KH, variant) key appears twice (the first match would silently win), and the rows of
+    tile 12 / 9 / 10 (the halo kernels) are 3 x 3 shapes."""
+    import collections
+    import os
+    import re
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "madm_amd", "csrc", "igemm_tuned.inc")
+    rows = []
+    for ln in open(inc):
+        m = re.match(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", ln)
+        if m:
+            rows.append(tuple(int(v) for v in m.groups()))
+    assert len(rows) > 250
+    dup = [k for k, n in collections.Counter(r[:6] for r in rows).items() if n > 1]
+    assert not dup, dup[:5]
+    for dtype, M, N, K, KH, variant, tile, sk in rows:
+        assert dtype in (0, 1) and M > 0 and N > 0 and K > 0 and KH in (1, 3) and 0 <= variant <= 3, (M, N, K)
+        assert 1 <= tile <= 17 and sk >= 1, (M, N, K, tile, sk)
+        if tile in (4, 5, 9, 10, 12):
+            assert KH == 3, (M, N, K, tile)
+        if variant in (1, 2, 3):
+            assert KH == 3, (M, N, K, variant)
