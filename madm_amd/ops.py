@@ -9,7 +9,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _debug, _lib
 from ._lib import (lib, check, Conv2dArgs, AttentionArgs, EPI_NONE, EPI_GEGLU, EPI_RELU, MADM_F32, MADM_BF16, MADM_F16,
                    ACT_NONE, ACT_SILU, ACT_RELU)
 
@@ -130,7 +130,7 @@ def _workspace(nbytes, device):
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
-    return ws
+    return _debug.poison(ws) if _debug.MODE else ws
 
 
 def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l=0, OH=None, OW=None,
