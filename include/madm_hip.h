@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MADM_ABI_VERSION 4
+#define MADM_ABI_VERSION 5
 
 typedef enum {
     MADM_OK = 0,
@@ -168,6 +168,10 @@ int madm_conv2d_can_post_groupnorm(const madm_conv2d_args* a);
  * 9 / 10 = halo conv3x3 x128 / x64 with LDS-DMA weights, 11 = LDS-DMA igemm 64x64 with the short ring
  * (used by bench.py to attribute time). */
 int madm_conv2d_pick_tile(const madm_conv2d_args* a);
+/* 1 when a row of the tuned table (madm_amd/csrc/igemm_tuned.inc, MADM_TUNED_FILE) decides this launch's tile / split-K, 0 when
+ * it falls through to the heuristics (tests/test_parity_gpu.py::test_bench_workloads_have_tuned_rows: a shape of the bench
+ * workloads without a row ran 2 x too long for a whole round). */
+int madm_conv2d_has_tuned_row(const madm_conv2d_args* a);
 /* tuning/debug aid: force the workgroup tile (0 = tuned table then heuristic, -1 = heuristic only,
  * 1..11 = the tile codes of madm_conv2d_pick_tile). */
 void madm_debug_set_conv_tile(int tile);

@@ -3,6 +3,25 @@
 #pragma once
 #include "igemm_common.hpp"
 
+// Block index -> (output-channel tile, image, patch row, patch column) without run-time integer divisions: the three divisors
+// are launch constants, so the host hands over their reciprocals m = ceil(2^32 / d) and the kernel takes q = umulhi(x, m),
+// exact while x * d < 2^32 (checked by the launcher); d == 1 passes m = 0 and means q = x.  (Three 32-bit divisions are ~120
+// VALU instructions in front of the first DMA of every block: 2.2 k clocks of set-up in the 8 x 16 kernel's stamps, round 4.)
+struct PatchDecode {
+    int patchesX, patchesPerImg;
+    unsigned m_tilesN, m_ppi, m_px;
+};
+__host__ inline unsigned patch_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+__host__ inline bool patch_decode_fill(PatchDecode& pd, int patchesX, int patchesY, int tilesN, long long blocks) {
+    pd.patchesX = patchesX; pd.patchesPerImg = patchesX * patchesY;
+    pd.m_tilesN = patch_magic((unsigned)tilesN); pd.m_ppi = patch_magic((unsigned)pd.patchesPerImg);
+    pd.m_px = patch_magic((unsigned)patchesX);
+    const unsigned long long lim = 0x100000000ull;
+    return (unsigned long long)blocks * (unsigned)tilesN < lim && (unsigned long long)blocks * (unsigned)pd.patchesPerImg < lim &&
+           (unsigned long long)pd.patchesPerImg * (unsigned)patchesX < lim;
+}
+__device__ __forceinline__ int magic_div(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }
+
 namespace {
 
 constexpr int TH = 8, TW = 16, HWD = TW + 2, HPIX = (TH + 2) * HWD;  // 180 halo pixels

@@ -25,7 +25,7 @@ __device__ unsigned long long g_c3d_stamps[256];
 #endif
 
 template <typename T, int BN, bool FUSE>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p, int patchesX, int patchesPerImg) {
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p, const PatchDecode pd) {
     C3D_STAMP(0);
     kernarg_touch<5>();
 #if defined(__HIP_DEVICE_COMPILE__)   // LDS address-space casts and gfx asm: device pass only (the host needs the stub)
@@ -56,11 +56,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_dma_kernel(const IgemmP p
         const int nb = gridDim.x, q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
-    const int tn = bid % p.tilesN, tm = bid / p.tilesN;
+    const int tm = magic_div(bid, pd.m_tilesN), tn = bid - tm * p.tilesN;
     const int n0 = tn * BN;
-    const int b = tm / patchesPerImg;
-    const int pr = tm - b * patchesPerImg;
-    const int py0 = (pr / patchesX) * TH, px0 = (pr % patchesX) * TW;
+    const int b = magic_div(tm, pd.m_ppi);
+    const int pr = tm - b * pd.patchesPerImg;
+    const int pry = magic_div(pr, pd.m_px);
+    const int py0 = pry * TH, px0 = (pr - pry * pd.patchesX) * TW;
 
     // ---- halo staging state (as conv3x3.hip) ----
     int pixoff[HI];
@@ -274,7 +275,12 @@ int launch_dma_one(const IgemmP& p0, hipStream_t s) {
     const int patchesX = (p.OW + TW - 1) / TW, patchesY = (p.OH + TH - 1) / TH;
     p.tilesN = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.B * patchesX * patchesY * p.tilesN), 1, (unsigned)p.splitk);
-    kern<<<grid, 256, lds, s>>>(p, patchesX, patchesX * patchesY);
+    PatchDecode pd;
+    if (!patch_decode_fill(pd, patchesX, patchesY, p.tilesN, (long long)grid.x)) {
+        madm_set_error("conv3x3 (LDS-DMA): grid of %u blocks too large for the reciprocal patch decode", grid.x);
+        return MADM_ERR_INVALID_ARG;
+    }
+    kern<<<grid, 256, lds, s>>>(p, pd);
     return madm_check_launch("conv3x3_halo_dma_kernel");
 }
 

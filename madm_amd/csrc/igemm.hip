@@ -1137,6 +1137,13 @@ int madm_conv2d_pick_tile(const madm_conv2d_args* a) {
     return pick_tile(a);
 }
 
+int madm_conv2d_has_tuned_row(const madm_conv2d_args* a) {
+    if (!a || !madm_dtype_ok(a->dtype)) return 0;
+    const int M = a->B * a->OH * a->OW, K = a->KH * a->KW * (a->C1 + a->C2);
+    if (h16_upsample_eligible(a) && find_tuned(a->dtype, M, a->N, K, a->KH, 2)) return 1;
+    return find_tuned(a->dtype, M, a->N, K, a->KH, variant_of(a)) ? 1 : 0;
+}
+
 int madm_conv2d_suggest_splitk(const madm_conv2d_args* a) {
     if (!a) return 1;
     const int bke = (8 * madm_epc(a->dtype));

@@ -81,16 +81,26 @@ def inference_on_dataset(model, data_loader, evaluator, streams=4, range_check=N
     from .pipeline import GraphedInference
     evaluator.reset()
     runners = {}
-    with torch.no_grad():
-        for idx, inputs in enumerate(data_loader):
-            shape = tuple(inputs[0]['target_second_modality'].shape)
-            runner = runners.get(shape)
-            if runner is None:
-                runner = runners[shape] = GraphedInference(model, inputs, streams=streams, range_check=range_check)
-            outputs, done, slot = runner.submit(inputs)
-            with torch.cuda.stream(runner.stream_of(slot)):
-                evaluator.process(inputs, outputs)
+    was_training = bool(getattr(model, "training", False))
+    if hasattr(model, "eval"):
+        model.eval()        # inference_context(model) of the reference (evaluator.py:142-155): eval mode, restored afterwards
+    try:
+        with torch.no_grad():
+            for idx, inputs in enumerate(data_loader):
+                shape = tuple(inputs[0]['target_second_modality'].shape)
+                runner = runners.get(shape)
+                if runner is None:
+                    runner = runners[shape] = GraphedInference(model, inputs, streams=streams, range_check=range_check)
+                outputs, done, slot = runner.submit(inputs)
+                with torch.cuda.stream(runner.stream_of(slot)):
+                    evaluator.process(inputs, outputs)
+            for runner in runners.values():
+                runner.drain()
+    finally:
+        # an exception (the deferred range assert, a loader error) must not leave work in flight on the runners' streams
         for runner in runners.values():
-            runner.drain()
+            runner.quiesce()
+        if was_training and hasattr(model, "train"):
+            model.train()
     results = evaluator.evaluate()
     return {} if results is None else results

@@ -32,6 +32,7 @@ class DDPMSchedule:
     def tables(self, device):
         key = str(device)
         if key not in self._dev:
+            # (a blocking host -> device copy: complete when .to() returns, so safe for every stream of the process)
             self._dev[key] = (self.sqrt_ac.to(device).contiguous(), self.sqrt_1mac.to(device).contiguous())
         return self._dev[key]
 
@@ -85,35 +86,56 @@ def vae_decoder(vae, latents, decoder_block_indices, output_final=False):
     return (None if sample is None else sample.nchw(3)), [t.nchw() for t in taps]
 
 
-_const_cache = {}
+class _StreamSafeCache(dict):
+    """Lazily built device constants shared by every stream of the process.  An entry is filled by kernels on whatever
+    stream is current at the first use (e.g. the EMA teacher's side stream, mtmadise.forward_train); a LATER user on another
+    stream must not read it before those kernels ran.  Each entry keeps the event recorded behind its fill until that event
+    has completed; users on other streams wait for it (free once complete: one query).  ``fills`` counts the misses.
+    Fills during a stream capture carry no event (the fill is a node of that graph; constants are built in the warm-up)."""
+    fills = 0
+
+    def get_or_build(self, key, build):
+        ent = self.get(key)
+        if ent is None:
+            val = build()
+            ev = st = None
+            t0 = val[0] if isinstance(val, tuple) else val
+            if t0.is_cuda and not torch.cuda.is_current_stream_capturing():
+                st = torch.cuda.current_stream(t0.device)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            self[key] = ent = [val, ev, st]
+            _StreamSafeCache.fills += 1
+            return val
+        val, ev, st = ent
+        if ev is not None and not torch.cuda.is_current_stream_capturing():
+            if ev.query():
+                ent[1] = ent[2] = None
+            else:
+                cur = torch.cuda.current_stream(st.device)
+                if cur != st:
+                    cur.wait_event(ev)
+        return val
+
+
+_const_cache = _StreamSafeCache()
 
 
 def _unit_tables(dev):
-    key = ("unit", str(dev))
-    if key not in _const_cache:
-        _const_cache[key] = (torch.ones(1, device=dev), torch.zeros(1, device=dev))
-    return _const_cache[key]
+    return _const_cache.get_or_build(("unit", str(dev)), lambda: (torch.ones(1, device=dev), torch.zeros(1, device=dev)))
 
 
 def _zeros(n, dev):
-    key = ("z", n, str(dev))
-    if key not in _const_cache:
-        _const_cache[key] = torch.zeros(n, device=dev)
-    return _const_cache[key]
+    return _const_cache.get_or_build(("z", n, str(dev)), lambda: torch.zeros(n, device=dev))
 
 
 def _const_timesteps(t, n, dev):
-    key = ("ts", int(t), n, str(dev))
-    if key not in _const_cache:
-        _const_cache[key] = torch.full((n,), int(t), dtype=torch.int64, device=dev)
-    return _const_cache[key]
+    return _const_cache.get_or_build(("ts", int(t), n, str(dev)),
+                                     lambda: torch.full((n,), int(t), dtype=torch.int64, device=dev))
 
 
 def _zeros_i64(n, dev):
-    key = ("zi", n, str(dev))
-    if key not in _const_cache:
-        _const_cache[key] = torch.zeros(n, dtype=torch.int64, device=dev)
-    return _const_cache[key]
+    return _const_cache.get_or_build(("zi", n, str(dev)), lambda: torch.zeros(n, dtype=torch.int64, device=dev))
 
 
 def add_noise(noise_scheduler, latents, timesteps, shared_noise=None):
@@ -130,7 +152,7 @@ def add_noise(noise_scheduler, latents, timesteps, shared_noise=None):
     return ops.nhwc_to_nchw(noisy, B, 4, h, w)
 
 
-_noise_cache = {}
+_noise_cache = _StreamSafeCache()
 
 
 def _sized_noise(shared_noise, hw):
@@ -139,11 +161,8 @@ def _sized_noise(shared_noise, hw):
     hw = tuple(int(v) for v in hw)
     if tuple(shared_noise.shape[2:]) == hw:
         return shared_noise
-    key = (shared_noise.data_ptr(), hw)
-    if key not in _noise_cache:
-        _noise_cache[key] = torch.nn.functional.interpolate(shared_noise, size=hw, mode="bicubic",
-                                                            align_corners=False).contiguous()
-    return _noise_cache[key]
+    return _noise_cache.get_or_build((shared_noise.data_ptr(), hw), lambda: torch.nn.functional.interpolate(
+        shared_noise, size=hw, mode="bicubic", align_corners=False).contiguous())
 
 
 def diffusion_unet(unet, sample, timestep, encoder_hidden_states, res_time_embedding, unet_block_indices,

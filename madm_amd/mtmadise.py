@@ -59,7 +59,7 @@ class MTMADISE(MadmInference):
         self.train_iter_index = 0
         self.ema_alpha, self.pseudo_threshold = ema_alpha, pseudo_threshold
         self.overlap_teacher = not bool(int(os.environ.get("MADM_NO_TEACHER_OVERLAP", "0")))
-        self._teacher_stream, self._teacher_warm = None, False
+        self._teacher_stream, self._teacher_warm = None, set()
         self.blur, self.color_jitter_strength, self.color_jitter_probability = blur, color_jitter_strength, color_jitter_probability
         self.enable_mixup, self.pl_crop, self.color_aug_flag = enable_mixup, pl_crop, color_aug_flag
         self.color_aug = color_aug        # callable(strong_parameters, data [N,3,H,W]) -> data; None: augment.strong_color
@@ -214,7 +214,11 @@ class MTMADISE(MadmInference):
         # same values; the Python-side random draws keep their order (random: two uniforms above, this randint; numpy: the
         # class choices below).  MADM_NO_TEACHER_OVERLAP=1 for A/B runs.
         main_stream = torch.cuda.current_stream(source.device)
-        overlap = self.overlap_teacher and self._teacher_warm
+        # ... per input geometry: a batch / crop size seen for the first time (a short last batch) runs in line, so whatever a
+        # first pass at that size builds lazily is built in ONE stream; the shared constant caches are stream-safe on top of
+        # that (ldm_rocm._StreamSafeCache: an entry filled on the side stream is waited for by its users on other streams)
+        warm_key = (B, tuple(source.shape[-2:]), tuple(target.shape[-2:]))
+        overlap = self.overlap_teacher and warm_key in self._teacher_warm
         side = main_stream
         if overlap:
             if self._teacher_stream is None:
@@ -238,7 +242,7 @@ class MTMADISE(MadmInference):
             ema_nchw = ops.nhwc_to_nchw(ema_logits.t, B, K, ema_logits.H, ema_logits.W)
             pseudo_prob, pseudo_label, pseudo_weight = L.pseudo_labels(ema_nchw, target.shape[2:], self.pseudo_threshold)
             del low_res_feats, ema_logits
-        self._teacher_warm = True
+        self._teacher_warm.add(warm_key)
 
         # ---- source pass ('default' adapter, input_modal 'rgb') ----
         self.set_lora_adapter(state='default')

@@ -72,6 +72,9 @@ def _skip_match(desc):
     return any(r.search(desc) for r in _SKIP_RE)
 
 
+# When TILE_LOG is a list, every forward conv / linear launch appends (description, tile code, split-K, has_tuned_row, FLOPs):
+# tests/test_parity_gpu.py::test_bench_workloads_have_tuned_rows
+TILE_LOG = None
 FUSE_GN = True   # fold GroupNorm(+SiLU) into eligible 3x3 convs (debug switch)
 # the GroupNorm that consumes a split-K conv rides on its reduction (conv2d(post_gn=...)); env MADM_NO_POST_GN for A/B runs
 POST_GN = not bool(int(os.environ.get("MADM_NO_POST_GN", "0")))
@@ -235,6 +238,10 @@ def conv2d(x1, w, B, IH, IW, *, N, x2=None, KH=1, KW=1, stride=1, pad_t=0, pad_l
         if ("tile%d" % lib.madm_conv2d_pick_tile(ctypes.byref(a))) in EXP_SKIP or _skip_match(
                 f"k{KH} s{stride}{' up' if upsample else ''} M{M} N{N} K{KH * KW * (C1 + C2)}"):
             return out if post_gn is None else (out, applied)
+    if TILE_LOG is not None:
+        TILE_LOG.append((f"dt{a.dtype} M{M} N{N} K{KH * KW * (C1 + C2)} k{KH} s{stride}{' up' if upsample else ''}"
+                         f"{' gn' if gn is not None else ''}", lib.madm_conv2d_pick_tile(ctypes.byref(a)), a.splitk,
+                         bool(lib.madm_conv2d_has_tuned_row(ctypes.byref(a))), 2.0 * M * N * KH * KW * (C1 + C2)))
     if PROFILE is None:
         check(lib.madm_conv2d_fwd(ctypes.byref(a), _stream()), "madm_conv2d_fwd")
     else:

@@ -175,12 +175,16 @@ class TableAdamW:
     def zero_grad(self):
         self.flat.grad.zero_()
 
-    def step(self, clip_grad=None, loss_scale=1.0, touched=None):
+    def step(self, clip_grad=None, loss_scale=1.0, touched=None, on_synced=None):
         """``touched``: ids of the parameters that received a gradient (None: all).  Returns (total gradient norm or None,
-        stepped: False when the norm is not finite -- GradScaler's inf / nan skip)."""
+        stepped: False when the norm is not finite -- GradScaler's inf / nan skip).  ``on_synced``: called right after the
+        step's one host sync and BEFORE any state is touched (MadmTrainer's deferred input-range assert: an exception there
+        leaves parameters, moments and step counts as they were)."""
         g = self.flat.grad
         scale = 1.0 / loss_scale
         norm = float(grad_sumsq(g).item()) ** 0.5 * scale       # one host sync (GradScaler.step syncs on found_inf too)
+        if on_synced is not None:
+            on_synced()
         if not (norm == norm and norm != float("inf")):
             return norm, False
         if clip_grad is not None:

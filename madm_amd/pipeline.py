@@ -46,9 +46,16 @@ class DeferredRangeCheck:
         self.tail = 0            # next entry to fill
         self.checked = 0
 
-    def push(self, minmax, stream, turn):
-        if self.tail - self.head >= self.depth:        # ring full: the oldest entry is `depth` submits old -- wait for it
+    def make_room(self):
+        """Called at the TOP of a submit, before anything of it is enqueued: polls, and if the ring is full waits for the oldest
+        entry (`depth` submits old).  An AssertionError of an earlier batch therefore never leaves a half-enqueued submit
+        behind -- ``push`` itself cannot raise."""
+        self.poll()
+        while self.tail - self.head >= self.depth:
             self._check(self.head, block=True)
+
+    def push(self, minmax, stream, turn):
+        assert self.tail - self.head < self.depth, "DeferredRangeCheck.push without make_room()"
         r = self.tail % self.depth
         self.host[r].copy_(minmax, non_blocking=True)
         self.events[r].record(stream)
@@ -75,6 +82,10 @@ class DeferredRangeCheck:
     def drain(self):
         while self.head < self.tail:
             self._check(self.head, block=True)
+
+    def discard(self):
+        """Forgets the pending entries (their events must have fired: call after the streams were synchronised)."""
+        self.head = self.tail
 
 
 class Submitted(tuple):
@@ -206,7 +217,6 @@ class StagedExtractor:
         self.encoded = [torch.cuda.Event() for _ in range(self.n_slots)]
         self.done = [torch.cuda.Event() for _ in range(self.n_slots)]
         self._ready = [torch.cuda.Event() for _ in range(2 * self.n_slots)]
-        self._taken = [torch.cuda.Event() for _ in range(2 * self.n_slots)]
         self.turn = 0
         if range_check is None:
             range_check = bool(ldm.check_input_range)
@@ -232,7 +242,7 @@ class StagedExtractor:
             assert not torch.is_tensor(got) and got == v, \
                 f"StagedExtractor: '{k_}' = {v!r} is fixed at construction (captured in the graphs), got {got!r}"
         if self.range_check is not None:
-            self.range_check.poll()
+            self.range_check.make_room()       # may raise an EARLIER batch's assert -- before anything of this submit is enqueued
         j = self.turn % self.n_slots
         first = self.turn < self.n_slots
         turn = self.turn
@@ -252,7 +262,7 @@ class StagedExtractor:
             # a hardware pipe with one of the four working ones)
             for k_ in self.tensor_keys:
                 _copy_checked(st[k_], batched_inputs.get(k_), k_, self.s_enc)
-            taken = self._taken[turn % len(self._taken)]
+            taken = torch.cuda.Event()         # one per submit: the caller may hold it for as long as it likes
             taken.record(self.s_enc)
             self.enc_graphs[j].replay()
             self.encoded[j].record(self.s_enc)
@@ -271,6 +281,13 @@ class StagedExtractor:
             s.synchronize()
         if self.range_check is not None:
             self.range_check.drain()
+
+    def quiesce(self):
+        """Waits for the streams and DROPS the pending range checks (error paths: leave nothing in flight, raise nothing)."""
+        for s in self.streams:
+            s.synchronize()
+        if self.range_check is not None:
+            self.range_check.discard()
 
     def concurrency_probe(self, reps=3):
         """Detects streams that share a hardware pipe: time of the k UNet graphs side by side on their k streams over k
@@ -348,7 +365,6 @@ class GraphedInference:
         torch.cuda.synchronize(dev)
         self.done = [torch.cuda.Event() for _ in range(self.n_slots)]
         self._ready = [torch.cuda.Event() for _ in range(2 * self.n_slots)]
-        self._taken = [torch.cuda.Event() for _ in range(2 * self.n_slots)]
         self.turn = 0
         if range_check is None:
             range_check = bool(ldm.check_input_range)
@@ -363,7 +379,7 @@ class GraphedInference:
         itself.  A device image must not be overwritten before ``.taken`` of the result has fired (see ``Submitted``)."""
         assert len(batched_inputs) == 1 and 'modality_type' not in batched_inputs[0]
         if self.range_check is not None:
-            self.range_check.poll()
+            self.range_check.make_room()
         j = self.turn % self.n_slots
         turn = self.turn
         self.turn += 1
@@ -380,7 +396,7 @@ class GraphedInference:
             self.static[j].copy_(x, non_blocking=True)          # dtype conversion (uint8 -> f32) included
             if x.is_cuda:
                 x.record_stream(s)
-            taken = self._taken[turn % len(self._taken)]
+            taken = torch.cuda.Event()
             taken.record(s)
             self.graphs[j].replay()
             if self.range_check is not None:
@@ -393,3 +409,10 @@ class GraphedInference:
             s.synchronize()
         if self.range_check is not None:
             self.range_check.drain()
+
+    def quiesce(self):
+        """Waits for the streams and DROPS the pending range checks (error paths: leave nothing in flight, raise nothing)."""
+        for s in self.streams_:
+            s.synchronize()
+        if self.range_check is not None:
+            self.range_check.discard()

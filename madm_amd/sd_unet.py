@@ -271,6 +271,16 @@ class Transformer2DModel(nn.Module):
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
         self.proj_out = Conv2d(inner, in_channels, 1)
 
+    def _proj_out_ff_stable(self):
+        """The composed operand pays where the weights stand still (inference, LoRA training over frozen base weights).  Layers
+        that are being trained -- or an EMA copy that moves every step -- would recompose Wp Wf (an f64 GEMM of 5 C^3 flops,
+        through the vendor BLAS: 6 x 296 us + the small ones per training step, round 5) on every step: they take the two-launch
+        path.  Trained = one of the four tensors requires grad; moving = the operand had to be rebuilt three times."""
+        ff2, po = self.transformer_blocks[0].ff.net[2], self.proj_out
+        if ff2.weight.requires_grad or po.weight.requires_grad or ff2.bias.requires_grad or po.bias.requires_grad:
+            return False
+        return self.__dict__.get("_po_rebuilds", 0) < 3
+
     def _proj_out_ff_operand(self, dtype):
         """[Wp | Wp Wf] (two gather sources: the residual stream h2 and the GEGLU output g) and Wp bf + bp: the block's last
         linear layer (ff.net[2], h3 = h2 + Wf g + bf) composed with proj_out (out = Wp h3 + bp + x) -- the same 5 C^2
@@ -281,6 +291,8 @@ class Transformer2DModel(nn.Module):
         hit = cache.get(dtype)
         if hit is not None and hit[0] == ver:
             return hit[1]
+        if hit is not None:
+            self.__dict__["_po_rebuilds"] = self.__dict__.get("_po_rebuilds", 0) + 1
         with torch.no_grad():
             wp64 = po.weight.detach().double().flatten(1)                      # [C, C]
             wf64 = ff2.weight.detach().double()                                # [C, 4C]
@@ -297,7 +309,7 @@ class Transformer2DModel(nn.Module):
         # the composed operand reads ff.net[2]'s own weight: a plain Linear only (an adapter wrapped around it -- a LoRA config
         # whose target_modules match 'net.2' -- takes the two-launch path, as the FOLD_LN paths do)
         if (FUSE_PROJ_OUT and len(self.transformer_blocks) == 1 and self.proj_out.n_pad == self.proj_out.out_channels
-                and type(self.transformer_blocks[0].ff.net[2]) is Linear):
+                and type(self.transformer_blocks[0].ff.net[2]) is Linear and self._proj_out_ff_stable()):
             h2, g = self.transformer_blocks[0](t, x.B, x.HW, ctx, Lk, defer_ff_out=True)
             wp, b = self._proj_out_ff_operand(h2.dtype)
             C = self.proj_out.out_channels
@@ -313,7 +325,7 @@ class Transformer2DModel(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k != "_po_cache":
+            if k not in ("_po_cache", "_po_rebuilds"):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 

@@ -160,7 +160,17 @@ class MadmTrainer:
         if self.lr_multiplier is not None:
             self.opt.lr_factor = float(self.lr_multiplier(self.iter))
         touched = getattr(model, "last_grad_param_ids", None)
-        norm, stepped = self.opt.step(clip_grad=self.grad_clip, loss_scale=self.scale, touched=touched)
+
+        def check_probes():
+            # the reference asserts before the batch is used (ldm_diffusers.py:147); here the three passes' probes are read at
+            # the step's first host sync -- forward and backward have run, but NOTHING persistent has consumed the batch yet:
+            # the optimizer step, the loss-scale update and the next step's EMA update are all behind this point
+            for i, mm in enumerate(probes):
+                lo, hi = mm.tolist()
+                assert -1 <= lo and hi <= 1, \
+                    f"input range check (ldm_diffusers.py:147), forward pass {i} of this step: min {lo} max {hi}"
+
+        norm, stepped = self.opt.step(clip_grad=self.grad_clip, loss_scale=self.scale, touched=touched, on_synced=check_probes)
         if self.amp:
             if not stepped:
                 self.scale *= self.backoff_factor
@@ -176,9 +186,6 @@ class MadmTrainer:
             self.last_allreduce_exposed_ms = ev[0].elapsed_time(ev[1])
             self.last_overlap_frac = self.reduced_during_backward / max(1, self.opt.flat.numel)
         out = {k: float(v.detach()) for k, v in loss_dict.items()}       # (the step's host sync)
-        for i, mm in enumerate(probes):
-            lo, hi = mm.tolist()
-            assert -1 <= lo and hi <= 1, f"input range check (ldm_diffusers.py:147), forward pass {i} of this step: min {lo} max {hi}"
         return out, norm, stepped
 
 

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.lib.madm_abi_version() == 4
+    assert _lib.lib.madm_abi_version() == 5
 
 
 def test_struct_layout_matches_header_field_order():
@@ -315,8 +315,10 @@ def test_shipped_code_has_no_low_lane_op_sel_packed_fp32():
     total, low, per = mod.scan(LIB_PATH)
     assert len(mod.code_objects(LIB_PATH)) >= 10, "no gfx950 code objects found in the library"
     assert low == 0, f"{low} packed-FP32 instructions feed a LOW result from a HIGH register"
-    stray = {k: v for k, v in per.items() if "conv3x3_h16_kernel" not in k}
-    assert not stray, f"packed-FP32 ops outside the 16 x 16 halo conv: {list(stray.items())[:5]}"
+    # (mangled names: conv3x3_h16_kernelIDF16_... = f16, ...IDF16b... = bf16, ...kernelIf... = float: the f32 instantiation is
+    # built without packed ops since round 6 -- conv3x3_h16_f32.hip)
+    stray = {k: v for k, v in per.items() if "conv3x3_h16_kernelIDF16" not in k}
+    assert not stray, f"packed-FP32 ops outside the 16-bit 16 x 16 halo conv: {list(stray.items())[:5]}"
 
 
 def test_lora_targets_outside_the_attention_projections_are_refused():

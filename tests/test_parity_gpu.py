@@ -532,3 +532,59 @@ def test_extractor_training_step_lora(cuda):
     for n, p in m.unet.named_parameters():
         if n in frozen:
             assert torch.equal(p.detach(), frozen[n]), n
+
+
+def test_bench_workloads_have_tuned_rows(cuda):
+    """VERDICT r5 #7 / DESIGN 12.3: the eval forward ran 2 x too long on two B = 1 shapes for a whole round because the launches
+    had silently left the tuned table.  Every forward conv / linear launch of the bench workloads at their shipped sizes --
+    extract (configs[1], f16 and bf16 share the rows), extract + one r = 8 adapter, eval (configs[2]), sliding windows
+    (configs[4] geometry) -- must be decided by a ROW of madm_amd/csrc/igemm_tuned.inc (madm_conv2d_has_tuned_row), not by the
+    fall-through heuristics; the message lists the missing rows in the table's own format (pinned to today's choice) so
+    that a kernel change that moves shapes is followed by a re-tune (tools/tune_concurrent.py) or an explicit row."""
+    import bench
+    from types import SimpleNamespace
+    from madm_amd import ops, weights
+    from madm_amd.ldm_rocm import LdmRocm
+    dev = torch.device("cuda")
+    misses = {}
+
+    def collect(tag, fn):
+        ops.TILE_LOG = []
+        try:
+            with torch.no_grad():
+                fn()
+            torch.cuda.synchronize()
+            for desc, tile, sk, has_row, flop in ops.TILE_LOG:
+                if not has_row:
+                    misses.setdefault(desc, [tile, sk, flop, set()])[3].add(tag)
+            n = len(ops.TILE_LOG)
+        finally:
+            ops.TILE_LOG = None
+        assert n > 50, (tag, n)
+
+    dt = torch.float16
+    m = LdmRocm("", encoder_block_indices=[], unet_block_indices=[5, 8, 11], decoder_block_indices=[], input_range='-1+1',
+                unet_block_indices_type='after', finetune_unet='no', compute_dtype=dt, weights='synthetic', seed=0, device=dev)
+    batch = bench.make_input_pool(2, 512, dev)[0]
+    collect("extract", lambda: m(batch, "rgb"))
+    m.unet.add_adapter(SimpleNamespace(r=8, lora_alpha=8, target_modules=["to_k", "to_q", "to_v", "to_out.0"]), "Depth")
+    m.unet.set_adapter(["Depth"])
+    weights.randomize_lora_B_(m.unet)
+    collect("extract+lora", lambda: m(batch, "rgb"))
+    del m
+    torch.cuda.empty_cache()
+    for tag, slide in (("eval", False), ("slide", True)):
+        model = bench.build_eval_model(dt, dev, slide=slide, num_classes=9 if slide else 11)
+        img = 255.0 * torch.rand((3, 512, 1024 if slide else 512), generator=torch.Generator().manual_seed(3))
+        collect(tag, lambda: model([{"target_second_modality": img.to(dev)}]))
+        del model
+        torch.cuda.empty_cache()
+    if misses:
+        import re
+        rows = []
+        for desc, (tile, sk, flop, tags) in sorted(misses.items(), key=lambda kv: -kv[1][2]):
+            g = re.match(r"dt(\d) M(\d+) N(\d+) K(\d+) k(\d) s(\d)( up)?( gn)?", desc)
+            var = 1 if g.group(8) else (2 if g.group(7) else 0)
+            rows.append(f"{{1, {g.group(2)}, {g.group(3)}, {g.group(4)}, {g.group(5)}, {var}, {tile}, {sk}}},   "
+                        f"// {'/'.join(sorted(tags))}: {flop / 1e9:.2f} GFLOP, no row (heuristic choice pinned)")
+        raise AssertionError(f"{len(rows)} launch shapes of the bench workloads are not in the tuned table:\n" + "\n".join(rows))

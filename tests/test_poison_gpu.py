@@ -44,3 +44,41 @@ def test_kernel_suite_under_hbm_poison(cuda, mode):
     r, tail = _run_under({"MADM_DEBUG_POISON_HBM": mode}, targets, ["-k", "not full_t0"])
     assert r.returncode == 0, f"a kernel reads HBM nobody wrote (or the harness failed):\n{tail}\n{r.stderr[-2000:]}"
     assert " passed" in tail
+
+
+def test_hbm_poison_harness_is_effective(cuda):
+    """Negative control of the harness itself: under MADM_DEBUG_POISON_HBM=1 an uninitialised device allocation holds NaNs, the
+    split-K workspace is re-poisoned on every hand-out, a graph replay re-poisons its captured intermediates, and a kernel
+    that reads a buffer nobody wrote propagates the NaN -- i.e. a green suite under the harness means something."""
+    code = r'''
+import torch, madm_amd
+from madm_amd import _debug, ops
+assert _debug.MODE == 1
+x = torch.empty((64, 64), device="cuda", dtype=torch.float16)
+assert torch.isnan(x).all()
+assert torch.isnan(torch.empty_like(x)).all() and torch.isnan(x.new_empty((3,))).all()
+assert int(torch.empty(4, dtype=torch.int32, device="cuda")[0]) == 0x7F7F7F7F
+ws = ops._workspace(1 << 16, x.device); ws.zero_(); ws = ops._workspace(1 << 16, x.device)
+assert int(ws[0]) == 0xFF and int(ws[-1]) == 0xFF
+# a GEMM over an uninitialised operand: the NaNs must reach the output (zero weights do not hide them)
+w = torch.zeros((64, 64), device="cuda", dtype=torch.float16)
+out = ops.linear(torch.empty((128, 64), device="cuda", dtype=torch.float16), w)
+assert torch.isnan(out).all()
+# a captured graph re-poisons its intermediates at every replay
+g = torch.cuda.CUDAGraph()
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    keep = torch.ones(8, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        t = torch.empty(8, device="cuda")
+        keep.copy_(t)
+    t.zero_(); g.replay(); torch.cuda.synchronize()
+assert torch.isnan(keep).all()
+n0 = _debug.COUNT["tensors"]
+assert n0 >= 6
+print("harness ok", _debug.COUNT)
+'''
+    env = dict(os.environ, MADM_DEBUG_POISON_HBM="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0 and "harness ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

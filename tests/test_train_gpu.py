@@ -355,6 +355,14 @@ def test_train_step_matches_fixture(cuda, variant, dtype):
     ltol_p = ptol if f32 else 3.5 * ltol_n
     bad = [e for e in errs if e[0] > (ltol_n if ".lora_" in e[2] else ntol) or e[1] > (ltol_p if ".lora_" in e[2] else ptol)]
     assert not bad, sorted(bad, key=lambda e: -e[1])[:8]
+    # the maximum over ~500 adapter tensors is a tail statistic and its gate (0.49) says little on its own -- the
+    # adapters as a population are held to the ordinary probe gate at their 99th percentile (all but the ~5 worst draws) and
+    # to the adapters' |g| gate at their median
+    lora_p = sorted(e[1] for e in errs if ".lora_" in e[2])
+    if lora_p and not f32:
+        q99, q50 = lora_p[min(len(lora_p) - 1, int(0.99 * len(lora_p)))], lora_p[len(lora_p) // 2]
+        print(f"   adapter tensors: probe error median {q50:.2e}, 99th percentile {q99:.2e}, max {lora_p[-1]:.2e} of {len(lora_p)}")
+        assert q99 <= ptol and q50 <= mtol, (q50, q99, ptol, mtol)
     assert med_p < mtol, (med_p, mtol)
     for k in z.files:
         if k.startswith("grad:"):
@@ -609,3 +617,81 @@ def test_trainer_step_through_rccl_single_rank(cuda, monkeypatch):
                 assert worst < 2e-2, worst                                # AdamW's first step: lr * sign-like update
     finally:
         d.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16], ids=["f32", "f16"])
+def test_teacher_side_stream_is_bit_identical_over_steps(cuda, dtype):
+    """the EMA teacher's forward on a side stream (MTMADISE.overlap_teacher, from the SECOND step of an
+    input geometry on) against the same steps in line (MADM_NO_TEACHER_OVERLAP=1 semantics): five seeded optimizer steps --
+    the fourth with a SHORT batch (B = 1: a geometry seen for the first time after the warm-up, lazily built constants of
+    that size) and the fifth at the first geometry again -- must give bit-identical teacher logits, pseudo labels /
+    weights, mixed labels, every loss and the same parameters at the end.  Same kernels, same values; only the stream of
+    the teacher pass differs."""
+    from madm_amd.train import MadmTrainer
+    from madm_amd import ldm_rocm
+    B = TRAIN_CASE["B"]
+    batches = [train_inputs(**dict(TRAIN_CASE, input_seed=TRAIN_CASE["input_seed"] + i)) for i in range(5)]
+    batches[3] = batches[3][:1]
+    runs = {}
+    for overlap in (False, True):
+        model = build_product_train(dtype, "train_depth_lora")
+        model.overlap_teacher = overlap
+        stu, tea = [], []
+        for data in batches:
+            sc = train_dropout_scales(len(data))
+            stu += [sc[0], sc[1]]
+            tea += [sc[2]]
+        model.sem_seg_head.dropout_scale_override = stu
+        model.ema_sem_seg_head.dropout_scale_override = tea
+        trainer = MadmTrainer(model, lr=1e-4, weight_decay=0.01, grad_clip=None, amp=(dtype != torch.float32))
+        random.seed(99)
+        np.random.seed(98)
+        torch.manual_seed(97)
+        ldm_rocm._const_cache.clear()      # both modes start with cold constant caches (the B = 1 entries are built in step 4)
+        ldm_rocm._noise_cache.clear()
+        rec = []
+        for data in batches:
+            losses, norm, stepped = trainer.run_step(data)
+            ls = model.last_step
+            rec.append(dict(losses=dict(losses), norm=float(norm), stepped=stepped,
+                            **{k: ls[k].detach().clone() for k in ("ema_logits", "pseudo_label", "pseudo_weight", "mixed_lbl",
+                                                                    "mixed_seg_weight", "source_logits", "target_logits")}))
+        torch.cuda.synchronize()
+        used_side = model._teacher_stream is not None
+        assert used_side == overlap
+        runs[overlap] = (rec, {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad})
+        del model, trainer
+        torch.cuda.empty_cache()
+    (a, pa), (b, pb) = runs[False], runs[True]
+    for i, (ra, rb) in enumerate(zip(a, b)):
+        assert ra["stepped"] == rb["stepped"]
+        for k in ("ema_logits", "pseudo_label", "pseudo_weight", "mixed_lbl", "mixed_seg_weight", "source_logits", "target_logits"):
+            assert torch.equal(ra[k], rb[k]), f"step {i}: {k} differs between the in-line and the side-stream teacher"
+        assert ra["losses"] == rb["losses"] and ra["norm"] == rb["norm"], (i, ra["losses"], rb["losses"])
+    for n in pa:
+        assert torch.equal(pa[n], pb[n]), f"parameter {n} differs after five steps"
+
+
+def test_trainer_range_assert_fires_before_the_optimizer_step(cuda):
+    """the deferred input-range assert of MadmTrainer.run_step (ldm_diffusers.py:147 raises before the batch
+    is used) is checked at the step's first host sync, BEFORE AdamW: a caller that catches the AssertionError continues with
+    bit-unchanged parameters, moments, step counts and loss scale."""
+    from madm_amd.train import MadmTrainer
+    model = build_product_train(torch.float32, "train_depth_lora_only")
+    trainer = MadmTrainer(model, lr=1e-3, weight_decay=0.05, grad_clip=None, amp=False)
+    random.seed(1)
+    np.random.seed(2)
+    good = train_inputs(**TRAIN_CASE)
+    trainer.run_step(good)                       # one ordinary step first (moments non-zero)
+    torch.cuda.synchronize()
+    flat0, m0, v0 = trainer.opt.flat.flat.clone(), trainer.opt.m.clone(), trainer.opt.v.clone()
+    steps0, scale0, it0 = list(trainer.opt.steps), trainer.scale, trainer.iter
+    bad = train_inputs(**TRAIN_CASE)
+    bad[1]["source_rgb"] = bad[1]["source_rgb"] * 1.5          # 0 .. 382: outside [-1, 1] after the normalisation
+    with pytest.raises(AssertionError, match="input range check"):
+        trainer.run_step(bad)
+    torch.cuda.synchronize()
+    assert torch.equal(trainer.opt.flat.flat, flat0) and torch.equal(trainer.opt.m, m0) and torch.equal(trainer.opt.v, v0)
+    assert list(trainer.opt.steps) == steps0 and trainer.scale == scale0 and trainer.iter == it0
+    losses, norm, stepped = trainer.run_step(good)             # and the trainer is still usable
+    assert stepped and all(np.isfinite(v) for v in losses.values())

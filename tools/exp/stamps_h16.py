@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from madm_amd import ops
 from madm_amd._lib import lib
 
+LDS_ALLOC = "--lds-alloc" in sys.argv
+if LDS_ALLOC:
+    sys.argv.remove("--lds-alloc")
 cin, cout, hw, gn, res = (int(x) for x in (sys.argv[1:6] + ["128", "128", "512", "0", "0"][len(sys.argv) - 1:]))
 B = 2
 DT = torch.float16 if os.environ.get("DT") == "f16" else torch.bfloat16
@@ -33,6 +36,13 @@ buf = (ctypes.c_ulonglong * n)()
 lib.madm_debug_read_h16_stamps.restype = ctypes.c_int
 assert lib.madm_debug_read_h16_stamps(buf, n) == 0
 t0 = buf[0]
+if LDS_ALLOC:   # HW_REG_LDS_ALLOC as the first 1024 blocks read it: which values tell the CU's two resident workgroups apart?
+    import collections
+    al = (ctypes.c_ulonglong * 4024)()
+    assert lib.madm_debug_read_h16_stamps(al, 4024) == 0
+    hist = collections.Counter(int(v) & 0xffffffff for v in al[3000:4024])
+    print("HW_REG_LDS_ALLOC values over blocks 0..1023:", ", ".join(f"{k:#010x} x {v}" for k, v in sorted(hist.items())))
+    print("first 32 blocks:", " ".join(f"{int(v) & 0xffffffff:#x}" for v in al[3000:3032]))
 print(f"cin {cin} cout {cout} {hw}x{hw} gn {gn} residual {res}: set-up {buf[1] - t0}, first DMAs issued +{buf[2] - buf[1]}, fold +{buf[3] - buf[2]}; "
       f"loop end at {buf[4] - t0}, epilogue {buf[5] - buf[4]}, total {buf[5] - t0}")
 big = (ctypes.c_ulonglong * 2008)()

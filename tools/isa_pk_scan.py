@@ -80,7 +80,7 @@ def scan(path):
     return total, low, per
 
 
-ALLOWED = "conv3x3_h16_kernel"     # the one kernel that keeps packed FP32 (op_sel_hi forms only)
+ALLOWED = "conv3x3_h16_kernelIDF16"     # the 16-bit instantiations of the one kernel that keeps packed FP32 (op_sel_hi forms only)
 
 if __name__ == "__main__":
     bad = 0
