@@ -29,9 +29,13 @@ constexpr int H16_FIRST_ROUND = 512;    // 256 CUs x 2 workgroups
 constexpr int H16_T = 16, H16_W = H16_T + 2, H16_PIX = H16_W * H16_W;   // 18 x 18 = 324 halo pixels
 
 #ifdef H16_STAMPS   // tools/exp/stamps_h16.py: shader-clock stamps of one block's wave 0 (debug build only)
-__device__ unsigned long long g_h16_stamps[4096];
+// two clocks per stamp: [i] = s_memtime (shader-clock counter: UNDER-counts while the chip's MFMA pipes are loaded, DESIGN.md
+// section 8) and [4096 + i] = s_memrealtime (constant 100 MHz: coarse, but real time); [8192 + 4 b ..] = per-block records of ALL
+// blocks: realtime at entry / at the end of the epilogue, HW_REG_HW_ID, HW_REG_LDS_ALLOC (tools/exp/stamps_h16.py --blocks)
+__device__ unsigned long long g_h16_stamps[8192 + 4 * 8192];
 #define H16_STAMP(i_)                                                                             \
-    if (stamp_on) { __builtin_amdgcn_sched_barrier(0); g_h16_stamps[(i_)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+    if (stamp_on) { __builtin_amdgcn_sched_barrier(0); g_h16_stamps[(i_)] = __builtin_readcyclecounter();                  \
+                    g_h16_stamps[4096 + (i_)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define H16_STAMP(i_)
 #endif
@@ -83,26 +87,23 @@ __device__ __forceinline__ void h16_epilogue(const IgemmP& p, f32x4 (&acc)[MI][B
     f32x4 cs[NI], cq[NI], add[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) { cs[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cq[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    if (p.splitk == 1) epilogue_consts<NI>(p, nb, b, add);
+    epilogue_consts<NI>(p, nb, b, add);
     int mrow[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int oy = py0 + wm * MI + i, ox = px0 + frow;
         mrow[i] = (oy < p.OH && ox < p.OW) ? (b * p.OH + oy) * p.OW + ox : -1;
     }
-    if (p.splitk > 1) {
+    {
+        // (split-K launches take h16_epilogue_splitk.)  Two patch rows at a time: epilogue_tile keeps the residual pieces of ALL its
+        // rows in flight, which for MI = 8 x NI = 4 is 128 registers beside the 128 accumulators -- the compiler spilled 600 .. 750
+        // VGPRs to scratch around it (every f32-mode launch of this kernel takes this epilogue).  Same operations per element,
+        // same order: bit-identical.
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            if (mrow[i] < 0) continue;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const f32x4 v = acc[i][j];
-                if (nb + 16 * j < p.N)
-                    *reinterpret_cast<float4*>(p.ws + ((size_t)z * p.M + mrow[i]) * p.N + nb + 16 * j) = make_float4(v[0], v[1], v[2], v[3]);
-            }
+        for (int h = 0; h < MI; h += 2) {
+            const int mr2[2] = {mrow[h], mrow[h + 1]};
+            epilogue_tile<T, 2, NI>(p, mr2, nb, add, false, *reinterpret_cast<f32x4 (*)[2][NI]>(&acc[h]));
         }
-    } else {
-        epilogue_tile<T, MI, NI>(p, mrow, nb, add, false, acc);
         if (want_stats) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -354,6 +355,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, con
 #ifdef H16_STAMPS
     if (stamp_on) g_h16_stamps[7] = __builtin_amdgcn_s_getreg((31 << 11) | 6);
     if (tid == 0 && blockIdx.z == 0 && blockIdx.x < 1024) g_h16_stamps[3000 + blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+    if (tid == 0 && blockIdx.z == 0 && blockIdx.x < 8192) {
+        g_h16_stamps[8192 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        g_h16_stamps[8192 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        g_h16_stamps[8192 + 4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+    }
 #endif
     const int tm = magic_div(bid, pd.m_tilesN), tn = bid - tm * p.tilesN;
     const int n0 = tn * BN;
@@ -604,6 +610,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, con
     else if constexpr (WIDE) h16_epilogue_lds<T, BN, MI>(p, acc, b, py0, px0, n0, smem_raw, lds0);
     else h16_epilogue<T, BN, MI>(p, acc, b, py0, px0, n0, z, reinterpret_cast<float*>(smem_raw));
     H16_STAMP(5);
+#ifdef H16_STAMPS
+    if (tid == 0 && blockIdx.z == 0 && blockIdx.x < 8192) g_h16_stamps[8192 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #endif
 }
 

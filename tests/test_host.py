@@ -321,6 +321,26 @@ def test_shipped_code_has_no_low_lane_op_sel_packed_fp32():
     assert not stray, f"packed-FP32 ops outside the 16-bit 16 x 16 halo conv: {list(stray.items())[:5]}"
 
 
+def test_shipped_kernels_use_no_scratch():
+    """Round 6: no kernel of the library may spill to scratch.  The generic epilogue of the 16 x 16 halo conv -- the one every
+    f32-mode launch takes -- spilled 400 .. 750 VGPRs (private segment 680 .. 876 B per lane) until it was split into two-row
+    steps; the only other scratch user the path ever had (the rejected weights-direct variant) was not bit-stable under the
+    multi-stream pipeline.  Read from the code objects' metadata (tools/scratch_scan.py)."""
+    import importlib.util
+    import shutil
+    from madm_amd._lib import LIB_PATH
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("scratch_scan", os.path.join(root, "tools", "scratch_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not (os.path.exists(mod.READELF) or shutil.which(mod.READELF)):
+        pytest.skip("llvm-readelf of the ROCm toolchain not found")
+    rows = mod.kernels(LIB_PATH)
+    assert len(rows) >= 250, f"only {len(rows)} kernels found in the library's code objects"
+    bad = {k: v for k, v in rows.items() if v.get("private_segment_fixed_size", 0) > 0 or v.get("vgpr_spill_count", 0) > 0}
+    assert not bad, f"kernels with scratch: {[(k[:80], v.get('private_segment_fixed_size')) for k, v in bad.items()][:6]}"
+
+
 def test_lora_targets_outside_the_attention_projections_are_refused():
     """the adapters run as K-extensions of the fused attention projections; a LoRA config whose target_modules
     match any other Linear (e.g. 'net.2', which Transformer2DModel composes with proj_out) must fail loudly at add_adapter,
