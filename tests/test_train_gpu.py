@@ -654,7 +654,7 @@ def test_teacher_side_stream_is_bit_identical_over_steps(cuda, dtype):
             losses, norm, stepped = trainer.run_step(data)
             ls = model.last_step
             rec.append(dict(losses=dict(losses), norm=float(norm), stepped=stepped,
-                            **{k: getattr(ls[k], "t", ls[k]).detach().clone()        # (the logits are Tok token tensors)
+                            **{k: (ls[k] if torch.is_tensor(ls[k]) else ls[k].t).detach().clone()        # (the logits are Tok token tensors)
                                for k in ("ema_logits", "pseudo_label", "pseudo_weight", "mixed_lbl", "mixed_seg_weight",
                                          "source_logits", "target_logits")}))
         torch.cuda.synchronize()
