@@ -257,13 +257,22 @@ def kernel_profile(model, inputs):
             ops.PROFILE, ops.PROFILE_DIFF = None, False
 
     raw = one_pass(False)
-    dif = one_pass(True)
-    assert [r[0] for r in raw] == [r[0] for r in dif]
+    # the differenced pass THREE times, per-launch median: one sample is at the mercy of a host hiccup between the second and
+    # the third launch of a bracket (round 6, first bench process on a fresh box: one small launch read 60 x its time and
+    # became the "dominant kernel" of the line)
+    difs = [one_pass(True) for _ in range(3)]
+    for dif in difs:
+        assert [r[0] for r in raw] == [r[0] for r in dif]
     agg, layers = {}, {}
-    for (name, flops, e0, e1, desc, nbytes, _p), (_, _, d0, d1, _, _, dp) in zip(raw, dif):
+    for i, (name, flops, e0, e1, desc, nbytes, _p) in enumerate(raw):
         n, ms, fl, by, dms = agg.get(name, (0, 0.0, 0.0, 0, 0.0))
         t_raw = e0.elapsed_time(e1)
-        t_dif = max(d1.elapsed_time(dp.e2) - d0.elapsed_time(d1), 1e-4) if dp.e2 is not None else t_raw
+        samples = []
+        for dif in difs:
+            _, _, d0, d1, _, _, dp = dif[i]
+            if dp.e2 is not None:
+                samples.append(max(d1.elapsed_time(dp.e2) - d0.elapsed_time(d1), 1e-4))
+        t_dif = sorted(samples)[len(samples) // 2] if samples else t_raw
         agg[name] = (n + 1, ms + t_raw, fl + flops, by + nbytes, dms + t_dif)
         row = layers.setdefault(name, {}).setdefault(desc, [0, 0.0, 0, 0.0])
         row[0] += 1

@@ -24,9 +24,6 @@
 
 namespace {
 
-constexpr int H16_STAGGER_DEFAULT = 0;
-constexpr int H16_TAP_PRIO_DEFAULT = 0;
-constexpr int H16_FIRST_ROUND = 512;    // 256 CUs x 2 workgroups
 constexpr int H16_T = 16, H16_W = H16_T + 2, H16_PIX = H16_W * H16_W;   // 18 x 18 = 324 halo pixels
 
 #ifdef H16_STAMPS   // tools/exp/stamps_h16.py: shader-clock stamps of one block's wave 0 (debug build only)
@@ -303,31 +300,12 @@ __device__ __forceinline__ void h16_epilogue_lds(const IgemmP& p, f32x4 (&acc)[M
 }
 
 template <typename T, int BN, bool FUSE, bool WIDE, bool SK>
-__global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, const PatchDecode pd, int stagger, int tap_prio) {
+__global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, const PatchDecode pd) {
     kernarg_touch<5>();
 #if defined(__HIP_DEVICE_COMPILE__)
-    // Phase stagger of the CU's two resident workgroups.  Both slots of a CU are filled at launch and every workgroup of a layer
-    // takes the same time, so the pair walks its phases (halo DMA -> GroupNorm pass -> 18 taps -> epilogue) in LOCKSTEP for the
-    // whole kernel: both in the VALU pass together, both in the MFMA loop together -- per SIMD the vector and matrix clocks of
-    // the two waves add instead of overlapping (PMC: MfmaUtil 41 % + VALU 42 %, round 5).  The workgroup that sits in the CU's
-    // upper LDS allocation (HW_REG_LDS_ALLOC.LDS_BASE != 0) of the FIRST round sleeps `stagger` clocks before it starts; equal
-    // durations keep the offset for the rest of the launch.
-    const bool upper_slot = (__builtin_amdgcn_s_getreg((31 << 11) | 6) & 0xfffu) != 0;    // HW_REG_LDS_ALLOC.LDS_BASE != 0
-    if (stagger > 0 && (int)blockIdx.x < H16_FIRST_ROUND && upper_slot) {
-        const long long t_end = (long long)__builtin_readcyclecounter() + stagger;
-        while ((long long)__builtin_readcyclecounter() < t_end) __builtin_amdgcn_s_sleep(8);
-    }
-    // Issue priority of this workgroup's waves inside the tap loop.  The two waves of a SIMD (one per resident workgroup) run
-    // the same tap program: 64 MFMAs (0.49 us of pipe time) + ~0.34 us of barrier / DMA issue / first-operand latency.  At
-    // EQUAL priority two ready waves share the matrix pipe 1 : 1, both finish their 64 MFMAs together and then both sit in their
-    // overhead together: a tap takes 0.98 + 0.34 us for the pair (measured in real time: 1.32 us, tools/exp/stamps_h16_rt.py)
-    // instead of the 0.98 us the pipe needs.  With the upper-slot workgroup at a higher priority its MFMAs go first and the
-    // lower-slot wave's fill the gaps.
-    const int loop_prio = upper_slot ? tap_prio : 0;
-#define H16_LOOP_PRIO()                                                                            \
-    { if (loop_prio == 1) __builtin_amdgcn_s_setprio(1); else if (loop_prio == 2) __builtin_amdgcn_s_setprio(2);           \
-      else if (loop_prio == 3) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
-    H16_LOOP_PRIO();
+    // (Round 6, measured and removed -- tools/exp/r6_h16_stagger_prio.patch, profiles/round6_h16_realtime.txt: delaying the
+    // workgroup in the CU's upper LDS allocation by 1.5 .. 16 k clocks, and running its tap loop at s_setprio 1 .. 3, both
+    // change no layer by more than the +-2 % run-to-run spread: the two resident workgroups are not in a harmful lockstep.)
     constexpr int EPC = TT<T>::EPC;
     constexpr int BKE = 8 * EPC;
     constexpr int MI = 8, NI = BN / 32;
@@ -519,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, con
             // take the issue arbitration (priority, then age -- MI355X_MICROARCH.md "Two waves per SIMD") for its duration
             __builtin_amdgcn_s_setprio(3);
             H16_TRANSFORM(ck);
-            H16_LOOP_PRIO();
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
         }
         H16_STAMP(stamp_i + 2);
@@ -662,16 +640,12 @@ int launch_h16_one(const IgemmP& p0, hipStream_t s) {
     const int patchesX = (p.OW + H16_T - 1) / H16_T, patchesY = (p.OH + H16_T - 1) / H16_T;
     p.tilesN = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.B * patchesX * patchesY * p.tilesN), 1, (unsigned)p.splitk);
-
-    // env MADM_H16_STAGGER=<clocks> (A/B knob; see the kernel's head)
-    static const int stagger = [] { const char* e = getenv("MADM_H16_STAGGER"); return e ? atoi(e) : H16_STAGGER_DEFAULT; }();
     PatchDecode pd;
     if (!patch_decode_fill(pd, patchesX, patchesY, p.tilesN, (long long)grid.x)) {
         madm_set_error("conv3x3 (16 x 16 patches): grid of %u blocks too large for the reciprocal patch decode", grid.x);
         return MADM_ERR_INVALID_ARG;
     }
-    static const int tap_prio = [] { const char* e = getenv("MADM_H16_TAP_PRIO"); return e ? atoi(e) : H16_TAP_PRIO_DEFAULT; }();
-    kern<<<grid, 256, lds, s>>>(p, pd, stagger, tap_prio);
+    kern<<<grid, 256, lds, s>>>(p, pd);
     return madm_check_launch("conv3x3_h16_kernel");
 }
 
