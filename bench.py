@@ -49,6 +49,7 @@ sys.path.insert(0, ROOT)
 ALG_FLOP_PER_IMAGE = 1.91993e12   # VAE-enc 1116.66 + UNet 803.27 GFLOP
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level table)
 PEAK_F32_TFLOPS = 157.3
+IN_KERNEL_GHZ = 1.9          # d s_memtime / d s_memrealtime inside conv3x3_h16 under load (profiles/round6_h16_realtime.txt)
 
 
 def parse():
@@ -338,11 +339,12 @@ def pmc_traffic(kernel, workload):
     try:
         raw = open(path, "rb").read()
         import hashlib
-        return (json.loads(raw)["kernels"][kernel]["hbm_bytes_per_launch"],
+        ent = json.loads(raw)["kernels"][kernel]
+        return (ent["hbm_bytes_per_launch"],
                 f"{rel}@sha256:{hashlib.sha256(raw).hexdigest()[:12]} (committed rocprofv3 --pmc passes of this command, "
-                "tools/pmc.sh; counters cannot be read from inside the process)")
+                "tools/pmc.sh; counters cannot be read from inside the process)", ent.get("sq"))
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None, None, None
 
 
 def usable_cores():
@@ -691,7 +693,7 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
             dom = max(prof.items(), key=lambda kv: kv[1][4])
             name, (n, ms_raw, fl, by, ms) = dom
             achieved = fl / (ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic(name, args.workload)
+            traffic, traffic_src, sq = pmc_traffic(name, args.workload)
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                                "traffic": traffic, "traffic_source": traffic_src,
@@ -707,6 +709,18 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
                                            "tflops": round(r[1] / (r[3] * 1e-3) / 1e12, 1),
                                            "algorithmic_mb_per_launch": round(r[2] / r[0] / 1e6, 2)}
                                           for d, r in sorted(layers[name].items(), key=lambda kv: -kv[1][3])]}
+            if sq and sq.get("kernel_us"):
+                # do vector and matrix work co-execute in the dominant kernel?  From the same committed
+                # PMC passes as `traffic` (p5 of tools/pmc.sh), mean over that kernel's dispatches; utilisations are per-SIMD busy
+                # cycles over the dispatch's wall time at IN_KERNEL_GHZ (the clock the chip holds inside this kernel, measured
+                # with s_memtime / s_memrealtime stamps: profiles/round6_h16_realtime.txt)
+                cyc = sq["kernel_us"] * 1e3 * IN_KERNEL_GHZ
+                out["roofline"]["pmc"] = {"mfma_util": round(sq["mfma_busy_cycles_per_simd"] / cyc, 3),
+                                          "valu_active": round(sq["valu_active_cycles_per_simd"] / cyc, 3),
+                                          "valu_mfma_coexec": round(sq["coexec_cycles_per_simd"] / cyc, 3),
+                                          "coexec_share_of_valu": sq["coexec_share_of_valu"],
+                                          "kernel_us_in_pass": sq["kernel_us"], "in_kernel_clock_ghz": IN_KERNEL_GHZ,
+                                          "source": traffic_src}
             out["kernels"] = {k: {"launches": v[0], "ms": round(v[4], 4), "ms_events_raw": round(v[1], 4),
                                   "tflops": round(v[2] / (v[4] * 1e-3) / 1e12, 2) if v[4] > 0 else None}
                               for k, v in sorted(prof.items(), key=lambda kv: -kv[1][4])}

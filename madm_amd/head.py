@@ -375,6 +375,7 @@ class DAFormerHead(nn.Module):
                 w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, N - w.shape[0]))
                 wp = packing.pack_conv_weight(w, dtype, ops.k_tile(dtype))              # [N, C]
                 c = (key, ops.pack_dgrad_weights(wp, 1))
+            ops.note_build()
             self.__dict__["_cls_dgrad_cache"] = c
         return c[1]
 
@@ -388,5 +389,6 @@ class DAFormerHead(nn.Module):
                 w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, Kp - w.shape[0]))
                 b = torch.nn.functional.pad(b, (0, Kp - b.shape[0])).contiguous()
                 c = (key, packing.pack_conv_weight(w, dtype, ops.k_tile(dtype)), b)
+            ops.note_build()
             self.__dict__["_cls_cache"] = c
         return c[1], c[2]

@@ -225,7 +225,9 @@ class MTMADISE(MadmInference):
                 self._teacher_stream = torch.cuda.Stream(device=source.device)
             side = self._teacher_stream
             side.wait_stream(main_stream)                 # inputs, and this step's EMA update, are in front of it
-        with torch.no_grad(), torch.cuda.stream(side):
+        # (operands the teacher pass builds lazily on the side stream -- it shares the student's UNet unless ema_w_unet -- are
+        # ordered in front of the main stream's passes one by one: ops.side_builds / ops.note_build)
+        with torch.no_grad(), torch.cuda.stream(side), ops.side_builds(main_stream):
             self.set_lora_adapter(state=tmod)
             kw = dict(input_modal='others', ema_forward=True)
             if self.rev_noise_sup and self.train_iter_index <= self.rev_noise_end_iter:

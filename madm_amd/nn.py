@@ -55,6 +55,7 @@ class _Packed(nn.Module):
             return hit[1]
         with torch.no_grad():
             val = build()
+        ops.note_build()       # built on a side stream beside the main one: main's consumers wait for it (ops.side_builds)
         cache[key] = (ver, val)
         return val
 

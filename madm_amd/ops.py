@@ -45,6 +45,46 @@ def _need_cuda(*ts):
 
 _workspaces = {}
 
+# ---- lazily built operands and side streams -------------------------------------------------------------------------------
+# Packed weights, composed operands and stacked K/V / time-embedding weights are built lazily by the FIRST forward that needs
+# them after a parameter change -- on whatever stream that forward runs.  When a pass runs on a side stream beside the main one
+# (the EMA teacher of mtmadise.forward_train shares the student's UNet and frozen VAE), an operand it builds there is consumed by
+# the main stream's passes a few host statements later with NO ordering between the two streams.  ``side_builds(main)`` is the
+# context such a pass runs in; every cache that stores a freshly built operand calls ``note_build()`` right after the build
+# kernels are enqueued: inside the context that records an event on the building stream and makes ``main`` wait for it (the
+# consumers on main are enqueued later on the host, so they are ordered behind the build).  Outside the context: nothing.
+_SIDE_BUILD_MAIN = None
+SIDE_BUILDS_NOTED = 0
+
+
+class side_builds:
+    def __init__(self, main_stream):
+        self.main = main_stream
+
+    def __enter__(self):
+        global _SIDE_BUILD_MAIN
+        self.prev, _SIDE_BUILD_MAIN = _SIDE_BUILD_MAIN, self.main
+        return self
+
+    def __exit__(self, *exc):
+        global _SIDE_BUILD_MAIN
+        _SIDE_BUILD_MAIN = self.prev
+        return False
+
+
+def note_build():
+    """Call after enqueueing the kernels that fill a cached operand (see ``side_builds``)."""
+    global SIDE_BUILDS_NOTED
+    main = _SIDE_BUILD_MAIN
+    if main is None or torch.cuda.is_current_stream_capturing():
+        return
+    cur = torch.cuda.current_stream(main.device)
+    if cur != main:
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        main.wait_event(ev)
+        SIDE_BUILDS_NOTED += 1
+
 # Optional per-launch profiler used by bench.py: when PROFILE is a list, every MFMA-kernel launch
 # appends (kernel name, algorithmic FLOPs, start event, end event) recorded on the launch stream.
 PROFILE = None

@@ -300,6 +300,7 @@ class Transformer2DModel(nn.Module):
             b = (wp64 @ ff2.bias.detach().double() + po.bias.detach().double()).float().contiguous()
             C = wp64.shape[0]
             packed = packing.pack_conv_weight(w[:, :, None, None].contiguous(), dtype, ops.k_tile(dtype), [C, 4 * C])
+        ops.note_build()
         cache[dtype] = (ver, (packed, b))
         return packed, b
 
@@ -551,6 +552,7 @@ class UNet2DConditionModel(nn.Module):
             with torch.no_grad():
                 W = torch.cat([w.detach().float() for w in ws], 0)
                 hit = (ver, packing.pack_linear_weight(W, ctx.dtype, ops.k_tile(ctx.dtype)))
+            ops.note_build()
             cache[ctx.dtype] = hit
         allkv = ops.linear(ctx, hit[1])
         kv, off = {}, 0
@@ -574,6 +576,7 @@ class UNet2DConditionModel(nn.Module):
                 b = torch.cat([r.time_emb_proj.bias.detach().float() for r in resnets], 0).contiguous()
                 Wp = packing.pack_linear_weight(W, emb.dtype, ops.k_tile(emb.dtype))
             hit = (ver, Wp, b)
+            ops.note_build()
             cache[emb.dtype] = hit
         _, Wp, b = hit
         rows = ops.rows_to_f32(ops.linear(ops.silu(emb), Wp, bias=b))
@@ -592,7 +595,7 @@ class UNet2DConditionModel(nn.Module):
         dtype = sample.t.dtype
         freqs = self.__dict__.get("_freqs")
         if freqs is None or freqs.device != sample.t.device:
-            freqs = ops.timestep_freqs(self.block_out_channels[0], sample.t.device)
+            freqs = ops.timestep_freqs(self.block_out_channels[0], sample.t.device)   # (a blocking host -> device copy: complete here)
             self.__dict__["_freqs"] = freqs
         t_emb = ops.timestep_embedding(timesteps, freqs, dtype)
         # emb = time_embedding(t_emb); emb += res_time_embedding (ldm_diffusers.py:505-509): the add is

@@ -15,12 +15,14 @@ pytestmark = pytest.mark.gpu
 F32_TOL = 1e-3
 BF16_L2_TOL = 4e-2
 F16_L2_TOL = 8e-3     # fp16 storage (10 mantissa bits): the reference's own autocast arithmetic (engine/train_loop.py:277)
-# Per-tensor gates of the golden comparisons = 2x the worst value observed on MI355X over the four cases
-# (profiles/round2_precision_f16_bf16.txt; f32: max-relative 2.6e-6 .. 6.0e-6, gate 20x that -- north_star's bound is 1e-3):
+# Per-tensor gates of the golden comparisons = 1.5x the worst value observed on MI355X over the four cases (round 6, VERDICT r5 #7:
+# were 2x -- wide enough to hide the regression of one layer; profiles/round5_precision_f16_bf16.txt, unchanged since round 2;
+# f32: max-relative 2.6e-6 .. 7.5e-6, gate ~15x that -- north_star's bound is 1e-3).  The arithmetic is deterministic: the same
+# values on every box; a kernel change that moves a rounding pattern moves them by a few per cent, not by 50 %.
 #            latents   sample    taps
 GOLD_TOL = {torch.float32: dict(latents=1e-4, sample=1e-4, tap=1e-4),          # max |a - b| / max |b|
-            torch.float16: dict(latents=4.0e-3, sample=4.5e-3, tap=5.0e-3),    # relative L2 (observed <= 1.97 / 2.22 / 2.52e-3)
-            torch.bfloat16: dict(latents=2.8e-2, sample=4.0e-2, tap=3.8e-2)}   # relative L2 (observed <= 1.37 / 1.95 / 1.89e-2)
+            torch.float16: dict(latents=3.0e-3, sample=3.3e-3, tap=3.75e-3),   # relative L2 (observed <= 2.02 / 2.21 / 2.49e-3)
+            torch.bfloat16: dict(latents=2.25e-2, sample=2.9e-2, tap=2.9e-2)}  # relative L2 (observed <= 1.49 / 1.91 / 1.93e-2)
 
 
 class _LoraConfig:

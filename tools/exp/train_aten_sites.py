@@ -34,9 +34,9 @@ for ev in prof.events():
         continue
     site = "?"
     for fr in ev.stack:
-        if ("madm_amd" in fr or "bench.py" in fr) and "site-packages" not in fr:
-            site = fr.split("/root/repo/")[-1] if "/root/repo/" in fr else fr
-            site = site[-90:]
+        if ("madm_amd/" in fr or "bench.py" in fr) and "site-packages" not in fr and "dist-packages" not in fr:
+            site = fr[fr.index("madm_amd/"):] if "madm_amd/" in fr else fr[fr.index("bench.py"):]
+            site = site[:90]
             break
     shp = str(ev.input_shapes)[:60] if ev.input_shapes else ""
     agg[(ev.name, site)] += 1

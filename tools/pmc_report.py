@@ -46,6 +46,14 @@ def main():
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[k][r["Counter_Name"]] += 1
     if as_json:
+        # kernel wall time per launch from the kernel traces of the p5 pass (the pass the SQ co-execution counters come from)
+        dur = collections.defaultdict(lambda: [0.0, 0])
+        for f in glob.glob(d + "/p5/**/*kernel_trace.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = bench_name(r["Kernel_Name"])
+                if k is not None:
+                    dur[k][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+                    dur[k][1] += 1
         out = {}
         for k, v in agg.items():
             if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
@@ -53,6 +61,15 @@ def main():
                 write = 1024.0 * v["WRITE_SIZE"] / cnt[k]["WRITE_SIZE"]
                 out[k] = {"hbm_bytes_per_launch": round(fetch + write), "fetch_bytes_per_launch": round(fetch),
                           "write_bytes_per_launch": round(write), "dispatches": cnt[k]["FETCH_SIZE"]}
+                # per-SIMD cycle counts per launch (1 024 SIMDs): _MFMA_BUSY_ counts cycles, the others quad-cycles
+                if "SQ_VALU_MFMA_COEXEC_CYCLES" in v:
+                    per = lambda c, q: v[c] / cnt[k][c] * q / 1024.0
+                    mf, va, co = per("SQ_VALU_MFMA_BUSY_CYCLES", 1), per("SQ_ACTIVE_INST_VALU", 4), per("SQ_VALU_MFMA_COEXEC_CYCLES", 4)
+                    out[k]["sq"] = {"mfma_busy_cycles_per_simd": round(mf), "valu_active_cycles_per_simd": round(va),
+                                    "coexec_cycles_per_simd": round(co), "coexec_share_of_valu": round(co / va, 3) if va else None,
+                                    "wave_cycles_per_slot": round(per("SQ_WAVE_CYCLES", 4) / 2.0),
+                                    "kernel_us": round(dur[k][0] / dur[k][1], 2) if dur[k][1] else None,
+                                    "dispatches": cnt[k]["SQ_VALU_MFMA_COEXEC_CYCLES"]}
         json.dump({"source": "tools/pmc.sh (separate --pmc passes, --kernel-trace only); FETCH_SIZE KB x2 (gfx950), "
                              "WRITE_SIZE KB; mean over the dispatches of each kernel in the traced run",
                    "kernels": out}, open(sys.argv[3], "w"), indent=1)
