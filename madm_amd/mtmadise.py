@@ -90,6 +90,9 @@ class MTMADISE(MadmInference):
         ldm = bb.feature_extractor.ldm_extractor
         if self.ema_w_unet:
             ldm.ema_unet = deepcopy(ldm.unet)
+            for m in ldm.ema_unet.modules():      # an EMA copy moves every step: no composed proj_out operand (sd_unet)
+                if m.__class__.__name__ == "Transformer2DModel":
+                    m.__dict__["weights_move"] = True
             self.ema_parms.append(ldm.ema_unet)
             self.updated_parms.append(ldm.unet)
         fe = bb.feature_extractor

@@ -273,13 +273,14 @@ class Transformer2DModel(nn.Module):
 
     def _proj_out_ff_stable(self):
         """The composed operand pays where the weights stand still (inference, LoRA training over frozen base weights).  Layers
-        that are being trained -- or an EMA copy that moves every step -- would recompose Wp Wf (an f64 GEMM of 5 C^3 flops,
-        through the vendor BLAS: 6 x 296 us + the small ones per training step, round 5) on every step: they take the two-launch
-        path.  Trained = one of the four tensors requires grad; moving = the operand had to be rebuilt three times."""
+        that are being trained -- or an EMA copy that moves every step (``weights_move``, set by MTMADISE on ``ema_unet``) --
+        would recompose Wp Wf (an f64 GEMM of 5 C^3 flops through the vendor BLAS: 6 x 296 us + the small ones per training
+        step, round 5) on every step: they take the two-launch path.  The answer is a property of the module's configuration,
+        never of its history: a pass must not change arithmetic between two steps (or two passes of one step)."""
         ff2, po = self.transformer_blocks[0].ff.net[2], self.proj_out
         if ff2.weight.requires_grad or po.weight.requires_grad or ff2.bias.requires_grad or po.bias.requires_grad:
             return False
-        return self.__dict__.get("_po_rebuilds", 0) < 3
+        return not self.__dict__.get("weights_move", False)
 
     def _proj_out_ff_operand(self, dtype):
         """[Wp | Wp Wf] (two gather sources: the residual stream h2 and the GEGLU output g) and Wp bf + bp: the block's last
@@ -291,8 +292,6 @@ class Transformer2DModel(nn.Module):
         hit = cache.get(dtype)
         if hit is not None and hit[0] == ver:
             return hit[1]
-        if hit is not None:
-            self.__dict__["_po_rebuilds"] = self.__dict__.get("_po_rebuilds", 0) + 1
         with torch.no_grad():
             wp64 = po.weight.detach().double().flatten(1)                      # [C, C]
             wf64 = ff2.weight.detach().double()                                # [C, 4C]
@@ -326,7 +325,7 @@ class Transformer2DModel(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k not in ("_po_cache", "_po_rebuilds"):
+            if k != "_po_cache":
                 new.__dict__[k] = copy.deepcopy(v, memo)
         return new
 
