@@ -90,6 +90,9 @@ def parse():
                          "PCIe-inclusive rate DESIGN.md section 6 quotes)")
     ap.add_argument("--hw-queues", type=int, default=8,
                     help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime default of 4)")
+    ap.add_argument("--eval-runner", default="graphed", choices=["graphed", "staged"],
+                    help="eval / slide workloads: whole-forward graphs on --streams streams (GraphedInference) or three stage "
+                         "graphs per image, encoder | UNet x --pipeline | decoder + head (StagedInference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--lora", action="store_true", help="enable one r=8 LoRA adapter (north_star variant)")
@@ -516,8 +519,11 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
             return pipe.submit(pool[i % len(pool)])[0]
         first_stream = pipe.s_enc
     elif graphed:
-        from madm_amd.pipeline import GraphedInference
-        runner = GraphedInference(model, pool[0], streams=max(1, args.streams), slots=max(1, args.graphs, args.streams))
+        from madm_amd.pipeline import GraphedInference, StagedInference
+        if args.eval_runner == "staged":
+            runner = StagedInference(model, pool[0], unet_streams=max(1, min(args.pipeline, 2)), slots=args.slots or None)
+        else:
+            runner = GraphedInference(model, pool[0], streams=max(1, args.streams), slots=max(1, args.graphs, args.streams))
 
         def step(i):
             return runner.submit(pool[i % len(pool)])[0]
@@ -542,7 +548,9 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
         step(i)
     torch.cuda.synchronize()
     serial_ms = None
-    if graphed and args.streams > 1:
+    if graphed and args.eval_runner == "staged":
+        serial_ms = None          # (the one-image-in-flight figure comes from the whole-forward runner: --eval-runner graphed)
+    elif graphed and args.streams > 1:
         serial_ms = serial_reference(runner.graphs[0], runner.streams_[0])
     elif not args.no_graph and not staged and args.streams > 1:
         serial_ms = serial_reference(graphs[0], streams[0])
@@ -638,7 +646,10 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
                       f"flight, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}; "
                       + fed.format("StagedExtractor") + "; serial_* = whole-forward graph, one batch in flight")
         elif graphed:
-            launch = (f"whole-forward hipGraphs (madm_amd/pipeline.py::GraphedInference) on {max(1, args.streams)} streams: "
+            launch = (f"three stage graphs per image (madm_amd/pipeline.py::StagedInference): VAE encoder | UNet on {runner.k} streams | "
+                      f"VAE decoder + projections + head, {runner.n_slots} slots; " + fed.format("StagedInference")
+                      ) if args.eval_runner == "staged" else (
+                      f"whole-forward hipGraphs (madm_amd/pipeline.py::GraphedInference) on {max(1, args.streams)} streams: "
                       f"{max(1, args.streams)} images in flight; " + fed.format("GraphedInference")
                       + "; serial_* = one image in flight")
         else:

@@ -70,7 +70,7 @@ class SemSegEvaluator:
         return {"sem_seg": res}
 
 
-def inference_on_dataset(model, data_loader, evaluator, streams=4, range_check=None):
+def inference_on_dataset(model, data_loader, evaluator, streams=4, range_check=None, runner="graphed"):
     """``inference_on_dataset`` of /root/reference/evaluation/evaluator.py:30-139 (the loop at :75-93) on the throughput
     launch path: every ``inputs`` of the loader goes through ``pipeline.GraphedInference.submit`` (whole-forward hipGraphs,
     ``streams`` images in flight) and ``evaluator.process`` is enqueued on the slot's stream right behind the forward --
@@ -78,7 +78,8 @@ def inference_on_dataset(model, data_loader, evaluator, streams=4, range_check=N
     One runner per image shape (the graphs are captured for a shape; DSEC / DELIVER / FMB test images have one size each).
     The extractor's input-range assert is deferred (pipeline.DeferredRangeCheck): it raises from a later iteration or at the
     end.  Returns ``evaluator.evaluate()`` ({} when it returns None, as the reference does)."""
-    from .pipeline import GraphedInference
+    from .pipeline import GraphedInference, StagedInference
+    assert runner in ("graphed", "staged")   # whole-forward graphs on `streams` streams | encoder / UNet / decoder + head stage graphs
     evaluator.reset()
     runners = {}
     was_training = bool(getattr(model, "training", False))
@@ -88,18 +89,19 @@ def inference_on_dataset(model, data_loader, evaluator, streams=4, range_check=N
         with torch.no_grad():
             for idx, inputs in enumerate(data_loader):
                 shape = tuple(inputs[0]['target_second_modality'].shape)
-                runner = runners.get(shape)
-                if runner is None:
-                    runner = runners[shape] = GraphedInference(model, inputs, streams=streams, range_check=range_check)
-                outputs, done, slot = runner.submit(inputs)
-                with torch.cuda.stream(runner.stream_of(slot)):
+                rn = runners.get(shape)
+                if rn is None:
+                    rn = runners[shape] = (StagedInference(model, inputs, range_check=range_check) if runner == "staged" else
+                                           GraphedInference(model, inputs, streams=streams, range_check=range_check))
+                outputs, done, slot = rn.submit(inputs)
+                with torch.cuda.stream(rn.stream_of(slot)):
                     evaluator.process(inputs, outputs)
-            for runner in runners.values():
-                runner.drain()
+            for rn in runners.values():
+                rn.drain()
     finally:
         # an exception (the deferred range assert, a loader error) must not leave work in flight on the runners' streams
-        for runner in runners.values():
-            runner.quiesce()
+        for rn in runners.values():
+            rn.quiesce()
         if was_training and hasattr(model, "train"):
             model.train()
     results = evaluator.evaluate()

@@ -367,6 +367,9 @@ class LdmRocm(nn.Module):
         want_grad = torch.is_grad_enabled() and self._wants_grad(batched_inputs, kwargs)
         with torch.no_grad():
             st = self._stage_encode(batched_inputs)
+            hook = self.__dict__.get("stage_hook")
+            if hook is not None:          # pipeline.StagedInference: the stage boundary of a whole-model forward (capture / stream switch)
+                hook("encoded")
             out = self._stage_unet(st, batched_inputs, _keep_for_grad=want_grad, **kwargs)
         if not want_grad:
             return out
@@ -472,6 +475,9 @@ class LdmRocm(nn.Module):
             sample, unet_taps = _unet_tokens(forward_unet, Tok(noisy, B, h, w), timesteps, text_prompt,
                                              res_time_embedding, self.unet_block_indices, self.unet_block_indices_type)
 
+        hook = self.__dict__.get("stage_hook")
+        if hook is not None:              # the UNet is done: what follows (VAE decoder branch, projections, head) is the third stage
+            hook("unet")
         # feature lists as channels-last Toks; converted to NCHW f32 at the API boundary unless the (HIP) backbone
         # asked for tokens (madm_amd.backbone passes _return_tokens=True)
         as_tok = bool(kwargs.get("_return_tokens", False))

@@ -416,3 +416,157 @@ class GraphedInference:
             s.synchronize()
         if self.range_check is not None:
             self.range_check.discard()
+
+
+class StagedInference:
+    """``MadmInference.forward`` (mtmadise.py:657-691) as THREE hipGraphs per slot -- VAE encoder | UNet | VAE decoder +
+    projections + head -- the whole-model analogue of ``StagedExtractor``.  The two chip-filling stages run on
+    streams of their own (encoder: high priority, the pipeline's pacemaker; decoder + head), the small-grid UNet stages of
+    consecutive images side by side on ``unet_streams`` streams: four streams = the four hardware pipes of the queue scheduler.
+    The stage boundaries are ``LdmRocm.stage_hook`` calls inside ONE ordinary ``model(batched_inputs)`` call: during capture the
+    hook ends the running stream capture and begins the next one on the next stage's stream, so every module between the
+    boundaries is captured exactly as the eager forward runs it (same kernels, same values: the slot outputs are bit-identical
+    to ``model(batched_inputs)``).  ``submit`` has ``GraphedInference``'s contract."""
+
+    def __init__(self, model, example_inputs, unet_streams=2, slots=None, sync_inputs=True, range_check=None):
+        self.model = model
+        self.k = int(unet_streams)
+        self.n_slots = int(slots or 2 * (self.k + 1))
+        assert self.k >= 1 and self.n_slots >= self.k
+        self.sync_inputs = bool(sync_inputs)
+        _queues_warning(self.k + 2, "StagedInference")
+        assert len(example_inputs) == 1
+        dev = next(model.parameters()).device
+        self.device = dev
+        ex = example_inputs[0]['target_second_modality']
+        ldm = model.backbone.feature_extractor.ldm_extractor
+        self.ldm = ldm
+        self.s_enc = torch.cuda.Stream(device=dev, priority=-1)
+        self.s_unet = [torch.cuda.Stream(device=dev) for _ in range(self.k)]
+        self.s_dec = torch.cuda.Stream(device=dev)
+        self.static, self.graphs, self.outs, self.minmax = [], [], [], []
+        cur = torch.cuda.current_stream(dev)
+        with torch.no_grad():
+            for j in range(self.n_slots):
+                stage_streams = [self.s_enc, self.s_unet[j % self.k], self.s_dec]
+                x = torch.empty(tuple(ex.shape), dtype=torch.float32, device=dev).copy_(ex)
+                call = [{'target_second_modality': x}]
+                for s in stage_streams:
+                    s.wait_stream(cur)
+                self._run_staged(call, stage_streams, capture=False)      # sizes the three streams' workspaces outside the capture
+                torch.cuda.synchronize(dev)
+                out, graphs = self._run_staged(call, stage_streams, capture=True)
+                self.static.append(x)
+                self.graphs.append(graphs)
+                self.outs.append(out)
+                self.minmax.append(getattr(ldm, "last_minmax", None))
+        torch.cuda.synchronize(dev)
+        self.encoded = [torch.cuda.Event() for _ in range(self.n_slots)]
+        self.unet_done = [torch.cuda.Event() for _ in range(self.n_slots)]
+        self.done = [torch.cuda.Event() for _ in range(self.n_slots)]
+        self._ready = [torch.cuda.Event() for _ in range(2 * self.n_slots)]
+        self.turn = 0
+        if range_check is None:
+            range_check = bool(ldm.check_input_range)
+        self.range_check = DeferredRangeCheck(dev) if (range_check and self.minmax[0] is not None) else None
+
+    def _run_staged(self, call, streams, capture):
+        """One ``model(call)`` whose three stages run on ``streams`` (eager: chained by events) or are captured into three graphs."""
+        ldm, dev = self.ldm, self.device
+        graphs, state = [], {"i": 0}
+        prev = torch.cuda.current_stream(dev)
+
+        def begin(i):
+            torch.cuda.set_stream(streams[i])
+            if capture:
+                g = torch.cuda.CUDAGraph()
+                g.capture_begin()
+                graphs.append(g)
+
+        def hook(_name):
+            i = state["i"]
+            if capture:
+                graphs[i].capture_end()
+            else:
+                ev = torch.cuda.Event()
+                ev.record(streams[i])
+                streams[i + 1].wait_event(ev)
+            state["i"] = i + 1
+            begin(i + 1)
+
+        assert ldm.__dict__.get("stage_hook") is None, "StagedInference: a stage hook is already installed on this extractor"
+        ldm.__dict__["stage_hook"] = hook
+        try:
+            begin(0)
+            out = self.model(call)
+            assert state["i"] == 2, f"StagedInference: expected two stage boundaries in the forward, saw {state['i']}"
+            if capture:
+                graphs[2].capture_end()
+        finally:
+            ldm.__dict__["stage_hook"] = None
+            torch.cuda.set_stream(prev)
+        if not capture:
+            for s in streams:
+                s.synchronize()
+        return out, graphs
+
+    @property
+    def streams_(self):
+        return [self.s_enc, *self.s_unet, self.s_dec]
+
+    def stream_of(self, slot):
+        """The stream the slot's LAST stage runs on: work enqueued there after ``submit`` is ordered behind the outputs."""
+        return self.s_dec
+
+    def submit(self, batched_inputs):
+        """Returns ``Submitted`` = (outputs, event, slot); see ``GraphedInference.submit``."""
+        assert len(batched_inputs) == 1 and 'modality_type' not in batched_inputs[0]
+        if self.range_check is not None:
+            self.range_check.make_room()
+        j = self.turn % self.n_slots
+        first = self.turn < self.n_slots
+        turn = self.turn
+        self.turn += 1
+        x = batched_inputs[0]['target_second_modality']
+        assert tuple(x.shape) == tuple(self.static[j].shape), \
+            f"StagedInference: captured for images of shape {tuple(self.static[j].shape)}, got {tuple(x.shape)}"
+        if self.sync_inputs and x.is_cuda:
+            ready = self._ready[turn % len(self._ready)]
+            ready.record(torch.cuda.current_stream(self.device))
+        g1, g2, g3 = self.graphs[j]
+        with torch.cuda.stream(self.s_enc):
+            if self.sync_inputs and x.is_cuda:
+                self.s_enc.wait_event(ready)
+            if not first:
+                self.s_enc.wait_event(self.done[j])         # the slot's buffers (all three stages') are free again
+            self.static[j].copy_(x, non_blocking=True)
+            if x.is_cuda:
+                x.record_stream(self.s_enc)
+            taken = torch.cuda.Event()
+            taken.record(self.s_enc)
+            g1.replay()
+            self.encoded[j].record(self.s_enc)
+            if self.range_check is not None:
+                self.range_check.push(self.minmax[j], self.s_enc, turn)
+        su = self.s_unet[j % self.k]
+        with torch.cuda.stream(su):
+            su.wait_event(self.encoded[j])
+            g2.replay()
+            self.unet_done[j].record(su)
+        with torch.cuda.stream(self.s_dec):
+            self.s_dec.wait_event(self.unet_done[j])
+            g3.replay()
+            self.done[j].record(self.s_dec)
+        return Submitted((self.outs[j], self.done[j], j), taken, turn)
+
+    def drain(self):
+        for s in self.streams_:
+            s.synchronize()
+        if self.range_check is not None:
+            self.range_check.drain()
+
+    def quiesce(self):
+        for s in self.streams_:
+            s.synchronize()
+        if self.range_check is not None:
+            self.range_check.discard()

@@ -338,6 +338,41 @@ def test_inference_on_dataset_pipelined_matches_serial_loop(cuda):
         inference_on_dataset(model, [loader[0], bad, loader[4], loader[6]], SemSegEvaluator(K, ignore_label=255))
 
 
+def test_staged_inference_matches_forward(cuda):
+    """pipeline.StagedInference (round 6: VAE encoder | UNet | decoder + projections + head as three stage graphs per image, the
+    boundaries taken by LdmRocm.stage_hook inside one ordinary model call): ten DIFFERENT images through six slots, up to six
+    in flight -> every sem_seg bit-identical to MadmInference.forward on that image; the evaluator chained on the last
+    stage's stream sees the same confusion matrix as the serial loop; the deferred range assert still fires."""
+    import numpy as np
+    from madm_amd.evaluation import SemSegEvaluator, inference_on_dataset
+    from madm_amd.pipeline import StagedInference
+    model = _build_product("DEPTH", torch.float16)
+    K = 11
+    g = torch.Generator().manual_seed(41)
+    imgs = [255.0 * torch.rand((3, 512, 512), generator=g) for _ in range(10)]
+    calls = [[{"target_second_modality": (im.to(torch.uint8) if i % 2 else im).cuda(),
+               "target_label": torch.randint(0, K, (1, 512, 512), generator=g)}] for i, im in enumerate(imgs)]
+    runner = StagedInference(model, calls[0], unet_streams=2, slots=6)
+    got = []
+    for c in calls:
+        out, done, slot = runner.submit(c)
+        with torch.cuda.stream(runner.stream_of(slot)):
+            got.append(out[0]["sem_seg"].clone())
+    runner.drain()
+    for i, c in enumerate(calls):
+        want = model(c)[0]["sem_seg"]
+        assert torch.equal(got[i], want), f"image {i}: staged forward differs from forward()"
+    ev, ev2 = SemSegEvaluator(K, ignore_label=255), SemSegEvaluator(K, ignore_label=255)
+    res = inference_on_dataset(model, calls, ev, runner="staged")
+    for c in calls:
+        ev2.process(c, model(c))
+    assert np.array_equal(ev.confusion(), ev2.confusion()) and res["sem_seg"]["mIoU"] == ev2.evaluate()["sem_seg"]["mIoU"]
+    bad = [{"target_second_modality": calls[0][0]["target_second_modality"] * 1.01 + 1.0, "target_label": calls[0][0]["target_label"]}]
+    with pytest.raises(AssertionError, match="input range check"):
+        inference_on_dataset(model, [calls[0], bad, calls[2], calls[4]], SemSegEvaluator(K, ignore_label=255), runner="staged")
+    assert model.backbone.feature_extractor.ldm_extractor.__dict__.get("stage_hook") is None
+
+
 def test_flat_adamw_ema_clip(cuda):
     """One-launch AdamW (+ folded unscale / clip) and EMA on flat fp32 storage against torch.optim.AdamW,
     clip_grad_norm_ and the reference's EMA formula (cmdise.py:337-349) on CPU."""
