@@ -172,6 +172,12 @@ int madm_conv2d_pick_tile(const madm_conv2d_args* a);
  * it falls through to the heuristics (tests/test_parity_gpu.py::test_bench_workloads_have_tuned_rows: a shape of the bench
  * workloads without a row ran 2 x too long for a whole round). */
 int madm_conv2d_has_tuned_row(const madm_conv2d_args* a);
+/* Tile / split-K table profile of the process (ABI 5): 0 = throughput -- the rows tuned with the layer's launches side by side on three
+ * streams, the default and what the graph runners of madm_amd/pipeline.py capture under; 1 = latency -- rows tuned for one launch on an
+ * idle chip are consulted first (a synchronous caller with one batch in flight: the reference's own loop,
+ * engine/train_loop.py:257-311 / evaluation/evaluator.py:75-93).  Both produce the same values up to summation order. */
+int madm_set_tuning_profile(int profile);
+int madm_get_tuning_profile(void);
 /* tuning/debug aid: force the workgroup tile (0 = tuned table then heuristic, -1 = heuristic only,
  * 1..11 = the tile codes of madm_conv2d_pick_tile). */
 void madm_debug_set_conv_tile(int tile);

@@ -108,6 +108,8 @@ SYMBOLS = [
     ("madm_conv2d_suggest_splitk", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_pick_tile", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_has_tuned_row", c_int, [ctypes.POINTER(Conv2dArgs)]),
+    ("madm_set_tuning_profile", c_int, [c_int]),
+    ("madm_get_tuning_profile", c_int, []),
     ("madm_conv2d_can_fuse_groupnorm", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_conv2d_can_post_groupnorm", c_int, [ctypes.POINTER(Conv2dArgs)]),
     ("madm_groupnorm_finalize", c_int, [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

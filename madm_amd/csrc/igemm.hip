@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <atomic>
 #include "igemm_common.hpp"
 
 namespace {
@@ -831,6 +832,15 @@ inline int variant_of(const madm_conv2d_args* a) { return a->gn_sums1 ? 1 : (a->
 const Tuned g_tuned[] = {
 #include "igemm_tuned.inc"
     {-1, 0, 0, 0, 0, 0, 0, 0}};
+// The table above is tuned for THROUGHPUT: rows chosen with three launches of the layer side by side (tools/tune_concurrent.py), the
+// neighbours a launch has under the runners of madm_amd/pipeline.py.  A synchronous caller -- the reference's loop calling forward()
+// with one batch in flight -- wants the choice that is fastest ALONE on an idle chip: more split-K, the tile that fills 256 CUs by
+// itself.  Profile 1 (madm_set_tuning_profile; ops.tuning_profile("latency")) puts these rows in front of the table; a shape without
+// one keeps its throughput row.
+const Tuned g_tuned_latency[] = {
+#include "igemm_tuned_latency.inc"
+    {-1, 0, 0, 0, 0, 0, 0, 0}};
+std::atomic<int> g_tuning_profile{0};
 
 // Run-time rows in front of the compiled-in table (A/B runs of tools/tune_concurrent.py without a rebuild): the file named
 // by MADM_TUNED_FILE holds one "dtype M N K KH variant tile splitk" row per line ('#' starts a comment); read once.
@@ -865,6 +875,9 @@ const Tuned* find_tuned(int dtype, int M, int N, int K, int KH, int variant) {
     if (g_tile_override != 0) return nullptr;
     for (const Tuned& t : tuned_overrides())
         if (t.dtype == dtype && t.M == M && t.N == N && t.K == K && t.KH == KH && t.variant == variant) return &t;
+    if (g_tuning_profile.load(std::memory_order_relaxed) == 1)
+        for (const Tuned* t = g_tuned_latency; t->dtype >= 0; ++t)
+            if (t->dtype == dtype && t->M == M && t->N == N && t->K == K && t->KH == KH && t->variant == variant) return t;
     for (const Tuned* t = g_tuned; t->dtype >= 0; ++t)
         if (t->dtype == dtype && t->M == M && t->N == N && t->K == K && t->KH == KH && t->variant == variant) return t;
     return variant == 3 ? find_tuned(dtype, M, N, K, KH, 0) : nullptr;
@@ -1125,6 +1138,13 @@ int madm_debug_read_glds_stamps(unsigned long long* host, int n) {
 #endif
 
 void madm_debug_set_conv_tile(int t) { g_tile_override = t; }
+
+int madm_set_tuning_profile(int profile) {
+    MADM_REQUIRE(profile == 0 || profile == 1, "set_tuning_profile: 0 = throughput (side-by-side rows), 1 = latency (lone-launch rows)");
+    g_tuning_profile.store(profile, std::memory_order_relaxed);
+    return MADM_OK;
+}
+int madm_get_tuning_profile(void) { return g_tuning_profile.load(std::memory_order_relaxed); }
 
 size_t madm_conv2d_workspace_bytes(const madm_conv2d_args* a) {
     if (!a || a->splitk <= 1) return 0;

@@ -365,7 +365,7 @@ class LdmRocm(nn.Module):
         # separately: madm_amd/pipeline.py runs the encoder stage of every batch on one stream and the UNet stages of
         # consecutive batches side by side on three
         want_grad = torch.is_grad_enabled() and self._wants_grad(batched_inputs, kwargs)
-        with torch.no_grad():
+        with torch.no_grad(), ops.sync_profile():       # (one batch in flight: the lone-launch rows; a no-op inside the graph runners)
             st = self._stage_encode(batched_inputs)
             hook = self.__dict__.get("stage_hook")
             if hook is not None:          # pipeline.StagedInference: the stage boundary of a whole-model forward (capture / stream switch)

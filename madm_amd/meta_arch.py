@@ -65,6 +65,10 @@ class MadmInference(nn.Module):
 
     @torch.no_grad()
     def forward(self, batched_inputs):
+        with ops.sync_profile():      # one image in flight: lone-launch rows (no-op inside GraphedInference / StagedInference)
+            return self._forward(batched_inputs)
+
+    def _forward(self, batched_inputs):
         assert len(batched_inputs) == 1
         assert 'modality_type' not in batched_inputs[0].keys()
         x = batched_inputs[0]['target_second_modality'].to(next(self.parameters()).device).float()

@@ -189,6 +189,10 @@ class MTMADISE(MadmInference):
         return self.forward_train(batched_inputs)
 
     def forward_train(self, batched_inputs):
+        with ops.sync_profile():       # eager launches, one step in flight: the lone-launch rows of the tile table
+            return self._forward_train(batched_inputs)
+
+    def _forward_train(self, batched_inputs):
         if self.train_iter_index > 0:
             self._update_ema(self.train_iter_index)
         with torch.no_grad():
@@ -402,6 +406,11 @@ class _TrainStepFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        with ops.sync_profile():
+            return _TrainStepFn._backward(ctx, *gouts)
+
+    @staticmethod
+    def _backward(ctx, *gouts):
         st = ctx.state
         model, names, ctxs, params = st["model"], st["names"], st["ctxs"], st["params"]
         crit = model.criterion

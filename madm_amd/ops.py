@@ -45,6 +45,47 @@ def _need_cuda(*ts):
 
 _workspaces = {}
 
+class tuning_profile:
+    """``with ops.tuning_profile("latency"):`` -- tile / split-K rows tuned for ONE launch on an idle chip in front of the
+    throughput table (madm_set_tuning_profile; process-wide, restored on exit).  ``"throughput"`` (the library default) is what
+    the graph runners capture under.  ``pin=True``: contexts opened inside this one WITHOUT pin are ignored -- the runners of
+    madm_amd/pipeline.py pin "throughput" around their warm-up and capture, so the ``sync_profile()`` that a plain synchronous
+    ``LdmRocm.forward`` / ``MTMADISE.forward_train`` opens (``SYNC_PROFILE``, "latency") does nothing in there."""
+    CODES = {"throughput": 0, "latency": 1}
+    _pinned = 0
+
+    def __init__(self, name, pin=False):
+        self.code, self.pin = self.CODES[name], bool(pin)
+        self.active = False
+
+    def __enter__(self):
+        if tuning_profile._pinned and not self.pin:
+            return self
+        self.active = True
+        self.prev = lib.madm_get_tuning_profile()
+        check(lib.madm_set_tuning_profile(self.code), "madm_set_tuning_profile")
+        if self.pin:
+            tuning_profile._pinned += 1
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            if self.pin:
+                tuning_profile._pinned -= 1
+            check(lib.madm_set_tuning_profile(self.prev), "madm_set_tuning_profile")
+            self.active = False
+        return False
+
+
+def sync_profile():
+    """The profile context of a synchronous (one batch in flight) forward / training step."""
+    return tuning_profile(SYNC_PROFILE)
+
+
+# profile of a plain synchronous forward() call (env MADM_SYNC_PROFILE=throughput for A/B runs and for bit-comparisons with the runners)
+SYNC_PROFILE = os.environ.get("MADM_SYNC_PROFILE", "latency")
+
+
 # ---- lazily built operands and side streams -------------------------------------------------------------------------------
 # Packed weights, composed operands and stacked K/V / time-embedding weights are built lazily by the FIRST forward that needs
 # them after a parameter change -- on whatever stream that forward runs.  When a pass runs on a side stream beside the main one

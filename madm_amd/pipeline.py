@@ -190,7 +190,9 @@ class StagedExtractor:
             self.static.append(d)
         self.enc_graphs, self.unet_graphs, self.slots, self.outs = [], [], [], []
         cur = torch.cuda.current_stream(dev)
-        with torch.no_grad():
+        # the graphs hold the THROUGHPUT rows of the tile table (launches of several batches side by side): pinned, so that nothing
+        # inside switches to the lone-launch profile of a synchronous forward (ops.tuning_profile)
+        with torch.no_grad(), ops.tuning_profile("throughput", pin=True):
             for j in range(self.n_slots):
                 self.s_enc.wait_stream(cur)
                 with torch.cuda.stream(self.s_enc):
@@ -346,7 +348,7 @@ class GraphedInference:
         self.streams_ = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
         self.static, self.graphs, self.outs, self.minmax = [], [], [], []
         cur = torch.cuda.current_stream(dev)
-        with torch.no_grad():
+        with torch.no_grad(), ops.tuning_profile("throughput", pin=True):
             for j in range(self.n_slots):
                 s = self.streams_[j % self.n_streams]
                 x = torch.empty(tuple(ex.shape), dtype=torch.float32, device=dev).copy_(ex)
@@ -446,7 +448,7 @@ class StagedInference:
         self.s_dec = torch.cuda.Stream(device=dev)
         self.static, self.graphs, self.outs, self.minmax = [], [], [], []
         cur = torch.cuda.current_stream(dev)
-        with torch.no_grad():
+        with torch.no_grad(), ops.tuning_profile("throughput", pin=True):
             for j in range(self.n_slots):
                 stage_streams = [self.s_enc, self.s_unet[j % self.k], self.s_dec]
                 x = torch.empty(tuple(ex.shape), dtype=torch.float32, device=dev).copy_(ex)

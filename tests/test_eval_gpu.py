@@ -326,8 +326,10 @@ def test_inference_on_dataset_pipelined_matches_serial_loop(cuda):
     ev = Recording(K, ignore_label=255)
     res = inference_on_dataset(model, loader, ev)
     ev2 = SemSegEvaluator(K, ignore_label=255)
+    from madm_amd import ops
     for i, inputs in enumerate(loader):
-        out = model(inputs)
+        with ops.tuning_profile("throughput", pin=True):     # the rows the runner's graphs were captured under (bit-for-bit comparison)
+            out = model(inputs)
         assert torch.equal(out[0]["sem_seg"], ev.seen[i]), f"image {i}: pipelined forward differs from forward()"
         ev2.process(inputs, out)
     assert np.array_equal(ev.confusion(), ev2.confusion()) and ev.confusion().sum() == 6 * 512 * 512 + 2 * 448 * 512
@@ -359,13 +361,16 @@ def test_staged_inference_matches_forward(cuda):
         with torch.cuda.stream(runner.stream_of(slot)):
             got.append(out[0]["sem_seg"].clone())
     runner.drain()
-    for i, c in enumerate(calls):
-        want = model(c)[0]["sem_seg"]
-        assert torch.equal(got[i], want), f"image {i}: staged forward differs from forward()"
+    from madm_amd import ops
+    with ops.tuning_profile("throughput", pin=True):         # the rows the stage graphs were captured under
+        for i, c in enumerate(calls):
+            want = model(c)[0]["sem_seg"]
+            assert torch.equal(got[i], want), f"image {i}: staged forward differs from forward()"
     ev, ev2 = SemSegEvaluator(K, ignore_label=255), SemSegEvaluator(K, ignore_label=255)
     res = inference_on_dataset(model, calls, ev, runner="staged")
-    for c in calls:
-        ev2.process(c, model(c))
+    with ops.tuning_profile("throughput", pin=True):
+        for c in calls:
+            ev2.process(c, model(c))
     assert np.array_equal(ev.confusion(), ev2.confusion()) and res["sem_seg"]["mIoU"] == ev2.evaluate()["sem_seg"]["mIoU"]
     bad = [{"target_second_modality": calls[0][0]["target_second_modality"] * 1.01 + 1.0, "target_label": calls[0][0]["target_label"]}]
     with pytest.raises(AssertionError, match="input range check"):

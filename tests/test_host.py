@@ -365,16 +365,25 @@ def test_tuned_table_rows_are_valid_and_unique():
     import collections
     import os
     import re
-    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "madm_amd", "csrc", "igemm_tuned.inc")
-    rows = []
-    for ln in open(inc):
-        m = re.match(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", ln)
-        if m:
-            rows.append(tuple(int(v) for v in m.groups()))
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "madm_amd", "csrc")
+
+    def read(name):
+        out = []
+        for ln in open(os.path.join(csrc, name)):
+            m = re.match(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", ln)
+            if m:
+                out.append(tuple(int(v) for v in m.groups()))
+        dup = [k for k, n in collections.Counter(r[:6] for r in out).items() if n > 1]
+        assert not dup, (name, dup[:5])
+        return out
+
+    rows = read("igemm_tuned.inc")
     assert len(rows) > 250
-    dup = [k for k, n in collections.Counter(r[:6] for r in rows).items() if n > 1]
-    assert not dup, dup[:5]
-    for dtype, M, N, K, KH, variant, tile, sk in rows:
+    lat = read("igemm_tuned_latency.inc")     # round 6: the latency profile's rows (madm_set_tuning_profile(1)), same format
+    base = {r[:6]: r[6:] for r in rows}
+    for r in lat:   # a latency row that repeats the throughput row is noise (and hides a stale pair when one of them is re-tuned)
+        assert base.get(r[:6]) != r[6:], r
+    for dtype, M, N, K, KH, variant, tile, sk in rows + lat:
         assert dtype in (0, 1) and M > 0 and N > 0 and K > 0 and KH in (1, 3) and 0 <= variant <= 3, (M, N, K)
         assert 1 <= tile <= 17 and sk >= 1, (M, N, K, tile, sk)
         if tile in (4, 5, 9, 10, 12):

@@ -168,8 +168,11 @@ def _distinct_batches(n, B, H, W):
 
 
 def _forward_each(m, batches):
+    from madm_amd import ops
     want = []
-    with torch.no_grad():
+    # (the runners capture under the THROUGHPUT rows of the tile table; a plain forward() would take the lone-launch rows of the
+    # latency profile -- other tiles / split-K, another summation order -- so the bit-for-bit reference runs pinned to the same rows)
+    with torch.no_grad(), ops.tuning_profile("throughput", pin=True):
         for b in batches:
             want.append([f.clone() for f in m(b, "rgb")])
     torch.cuda.synchronize()

@@ -16,7 +16,12 @@ data = bench.train_inputs(2, 512, dev)
 for _ in range(2):
     trainer.run_step(data)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
+# (torch 2.10: Python stacks of CPU events need the experimental verbose config)
+try:
+    _cfg = torch._C._profiler._ExperimentalConfig(verbose=True)
+except Exception:
+    _cfg = None
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True, experimental_config=_cfg) as prof:
     trainer.run_step(data)
     torch.cuda.synchronize()
 LAUNCHING = {"aten::copy_", "aten::fill_", "aten::zero_", "aten::cat", "aten::mul", "aten::add", "aten::add_", "aten::mul_",

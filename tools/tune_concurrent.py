@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--min-us", type=float, default=50.0, help="skip shape classes whose launches sum to less (eager events)")
     ap.add_argument("--max-m", type=int, default=8192, help="largest M tuned (the VAE's 512^2 .. 128^2 maps lie above)")
     ap.add_argument("--rows", default="", help="write MADM_TUNED_FILE rows of the side-by-side winners here")
+    ap.add_argument("--alone-rows", default="", help="write the LONE-launch winners here (rows of the latency profile: "
+                    "madm_amd/csrc/igemm_tuned_latency.inc via tools/apply_alone_rows.py)")
     ap.add_argument("--only", default="", help="regex on the shape description")
     ap.add_argument("--lora", action="store_true", help="extract workload with one r = 8 adapter active (bench.py --lora): the "
                     "K-extended projection GEMMs and the skinny x A^T GEMMs get rows of their own")
@@ -193,7 +195,7 @@ def main():
         if mm:
             table_keys.add(tuple(int(mm.group(i)) for i in (2, 3, 4, 5, 6)))
     streams = [torch.cuda.Stream() for _ in range(args.streams)]
-    rows, tot = [], collections.defaultdict(float)
+    rows, arows, tot = [], [], collections.defaultdict(float)
     print(f"{'shape':44s} {'n':>3s} | {'current':>9s} {'alone':>7s} {'side':>7s} | {'best alone':>10s} {'us':>7s} | {'best side':>10s} {'alone':>7s} {'side':>7s}")
     for key, c in sorted(classes.items(), key=lambda kv: -kv[1]["us"]):
         d = parse_desc(c["desc"])
@@ -243,6 +245,8 @@ def main():
         variant = 1 if d["gn"] else (2 if d["up"] else (3 if d["s"] == 2 else 0))
         if args.workload == "train" and (d["M"], d["N"], d["K"], d["k"], variant) in table_keys:
             continue   # (a shape of the extractor's table: tuned side by side, not to be replaced by a lone-launch choice)
+        if ba[1][0] < 0.97 * cur[0]:
+            arows.append(f"1 {d['M']} {d['N']} {d['K']} {d['k']} {variant} {ba[0][0]} {ba[0][1]}   # alone {cur[0]:.1f} -> {ba[1][0]:.1f} us x {n} launches, side {cur[1]:.1f} -> {ba[1][1]:.1f}")
         if bs[1][1] < 0.97 * cur[1]:
             rows.append(f"1 {d['M']} {d['N']} {d['K']} {d['k']} {variant} {bs[0][0]} {bs[0][1]}   # side {cur[1]:.1f} -> {bs[1][1]:.1f} us, alone {cur[0]:.1f} -> {bs[1][0]:.1f}")
         del layers
@@ -253,6 +257,12 @@ def main():
             f.write("# dtype M N K KH variant tile splitk -- tools/tune_concurrent.py, side-by-side winners\n")
             f.write("\n".join(rows) + "\n")
     print("\n".join(rows))
+    if args.alone_rows:
+        with open(args.alone_rows, "w") as f:
+            f.write("# dtype M N K KH variant tile splitk -- tools/tune_concurrent.py, lone-launch winners (latency profile)\n")
+            f.write("\n".join(arows) + "\n")
+    print("lone-launch rows:")
+    print("\n".join(arows))
 
 
 if __name__ == "__main__":
