@@ -247,14 +247,18 @@ def kernel_profile(model, inputs):
     Returns ({kernel: (launches, raw_ms, algorithmic_flops, algorithmic_bytes, differenced_ms)},
              {kernel: {layer description "M.. N.. K.. ...": [launches, flops, bytes, differenced_ms]}})."""
     from madm_amd import ops
-    for _ in range(2):
-        model(*inputs)
+    # the table describes the kernels of the TIMED region: the runners capture under the throughput rows of the tile table, so the
+    # eager profiling passes are pinned to them too (a plain forward() would take the lone-launch rows of the latency profile)
+    with ops.tuning_profile("throughput", pin=True):
+        for _ in range(2):
+            model(*inputs)
     torch.cuda.synchronize()
 
     def one_pass(diff):
         ops.PROFILE, ops.PROFILE_DIFF = [], diff
         try:
-            model(*inputs)
+            with ops.tuning_profile("throughput", pin=True):
+                model(*inputs)
             torch.cuda.synchronize()
             return ops.PROFILE
         finally:
@@ -548,10 +552,8 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
         step(i)
     torch.cuda.synchronize()
     serial_ms = None
-    if graphed and args.eval_runner == "staged":
-        serial_ms = None          # (the one-image-in-flight figure comes from the whole-forward runner: --eval-runner graphed)
-    elif graphed and args.streams > 1:
-        serial_ms = serial_reference(runner.graphs[0], runner.streams_[0])
+    if graphed:
+        serial_ms = None          # measured after the timed region on a whole-forward graph of a synchronous forward() (below)
     elif not args.no_graph and not staged and args.streams > 1:
         serial_ms = serial_reference(graphs[0], streams[0])
     if dist is not None:
@@ -625,6 +627,11 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
                 torch.cuda.empty_cache()
         gs_, _, sts_ = capture_whole_forward(1, 1)
         serial_ms = serial_reference(gs_[0], sts_[0])
+    elif graphed:
+        # one image in flight: the whole-forward graph of a synchronous model(batched_inputs) call -- captured under the latency
+        # profile of the tile table (ops.sync_profile), unlike the runner's graphs
+        gs_, _, sts_ = capture_whole_forward(1, 1)
+        serial_ms = serial_reference(gs_[0], sts_[0])
 
     if rank == 0:
         images = args.batch * world * args.steps
@@ -644,14 +651,15 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
             launch = (f"staged hipGraph pipeline (madm_amd/pipeline.py): VAE-encoder graphs on 1 stream, UNet graphs on "
                       f"{args.pipeline} streams, {pipe.n_slots} slots, up to {pipe.n_slots + 1} batches ({(pipe.n_slots + 1) * args.batch} images) in "
                       f"flight, GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}; "
-                      + fed.format("StagedExtractor") + "; serial_* = whole-forward graph, one batch in flight")
+                      + fed.format("StagedExtractor") + "; serial_* = whole-forward graph of a synchronous forward() (the "
+                      "latency profile of the tile table: lone-launch rows), one batch in flight")
         elif graphed:
             launch = (f"three stage graphs per image (madm_amd/pipeline.py::StagedInference): VAE encoder | UNet on {runner.k} streams | "
                       f"VAE decoder + projections + head, {runner.n_slots} slots; " + fed.format("StagedInference")
                       ) if args.eval_runner == "staged" else (
                       f"whole-forward hipGraphs (madm_amd/pipeline.py::GraphedInference) on {max(1, args.streams)} streams: "
                       f"{max(1, args.streams)} images in flight; " + fed.format("GraphedInference")
-                      + "; serial_* = one image in flight")
+                      + "; serial_* = one image in flight (whole-forward graph of a synchronous call: latency profile of the tile table)")
         else:
             launch = ("hipGraph replay of ONE captured batch, 1 stream: one batch in flight" if args.streams <= 1 else
                       f"hipGraph replay of ONE captured batch on {args.streams} streams: {args.streams} batches in flight; "

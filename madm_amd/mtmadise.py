@@ -58,7 +58,13 @@ class MTMADISE(MadmInference):
         self.criterion = criterion
         self.train_iter_index = 0
         self.ema_alpha, self.pseudo_threshold = ema_alpha, pseudo_threshold
-        self.overlap_teacher = not bool(int(os.environ.get("MADM_NO_TEACHER_OVERLAP", "0")))
+        # The EMA teacher's forward on a side stream beside the student's source pass: OFF by default since round 6.  Made race-free
+        # (operands the teacher builds lazily on the side stream are ordered in front of main one by one: ops.side_builds), the
+        # student trails the teacher layer by layer and the step is 0.4 .. 1.4 % SLOWER than in line (same box, three runs each:
+        # 228.8 / 227.9 / 234.1 vs 225.7 / 224.4 / 233.1 ms, profiles/round6_ab_train_teacher_stream.txt); round 5's +1.5 % was
+        # measured with the race in place.  MADM_TEACHER_OVERLAP=1 switches it on (tested: tests/test_train_gpu.py).
+        self.overlap_teacher = bool(int(os.environ.get("MADM_TEACHER_OVERLAP", "0"))) and \
+            not bool(int(os.environ.get("MADM_NO_TEACHER_OVERLAP", "0")))
         self._teacher_stream, self._teacher_warm = None, set()
         self.blur, self.color_jitter_strength, self.color_jitter_probability = blur, color_jitter_strength, color_jitter_probability
         self.enable_mixup, self.pl_crop, self.color_aug_flag = enable_mixup, pl_crop, color_aug_flag
