@@ -390,3 +390,50 @@ def test_tuned_table_rows_are_valid_and_unique():
             assert KH == 3, (M, N, K, tile)
         if variant in (1, 2, 3):
             assert KH == 3, (M, N, K, variant)
+
+
+def test_tuning_profiles_switch_rows_and_pin():
+    """Round 6: madm_set_tuning_profile(1) puts the lone-launch rows of igemm_tuned_latency.inc in front of the throughput
+    table; ops.tuning_profile restores the previous profile on exit, and a pinned context (the graph runners: "throughput") makes the
+    sync_profile() of a synchronous forward inside it a no-op.  Host-side only: pick_tile / suggest_splitk need no GPU."""
+    import ctypes
+    import re
+    from madm_amd import ops
+    from madm_amd._lib import lib, Conv2dArgs, MADM_F16
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "madm_amd", "csrc")
+
+    def rows(name):
+        out = {}
+        for ln in open(os.path.join(csrc, name)):
+            m = re.match(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", ln)
+            if m:
+                v = tuple(int(x) for x in m.groups())
+                out[v[:6]] = v[6:]
+        return out
+
+    base, lat = rows("igemm_tuned.inc"), rows("igemm_tuned_latency.inc")
+    assert len(lat) >= 20
+    # a plain linear-layer shape (KH = 1, variant 0) whose two rows name different igemm tiles
+    key = next(k for k in sorted(lat) if k[4] == 1 and k[5] == 0 and k in base and base[k][0] != lat[k][0]
+               and lat[k][0] != 13 and base[k][0] != 13)
+    _, M, N, K, _, _ = key
+    a = Conv2dArgs()
+    a.dtype, a.C1, a.C2, a.B, a.IH, a.IW, a.OH, a.OW = MADM_F16, K, 0, 1, M, 1, M, 1
+    a.KH = a.KW = a.stride = 1
+    a.N, a.splitk = N, 1
+    a.in1 = a.w = a.out = 1
+    pick = lambda: (lib.madm_conv2d_pick_tile(ctypes.byref(a)), lib.madm_conv2d_suggest_splitk(ctypes.byref(a)))
+    assert lib.madm_get_tuning_profile() == 0 and pick() == base[key]
+    with ops.tuning_profile("latency"):
+        assert lib.madm_get_tuning_profile() == 1 and pick() == lat[key]
+        with ops.tuning_profile("throughput", pin=True):           # a runner's capture
+            assert pick() == base[key]
+            with ops.sync_profile():                                # a forward() inside it: ignored
+                assert lib.madm_get_tuning_profile() == 0 and pick() == base[key]
+            assert lib.madm_get_tuning_profile() == 0
+        assert lib.madm_get_tuning_profile() == 1
+    assert lib.madm_get_tuning_profile() == 0 and ops.tuning_profile._pinned == 0
+    with ops.sync_profile():
+        assert lib.madm_get_tuning_profile() == (1 if ops.SYNC_PROFILE == "latency" else 0)
+    assert lib.madm_set_tuning_profile(7) != 0 and b"profile" in lib.madm_last_error()
+    assert lib.madm_get_tuning_profile() == 0
