@@ -544,6 +544,11 @@ class _UNetTapsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        with ops.sync_profile():          # eager launches of a synchronous training step: the lone-launch rows
+            return _UNetTapsFn._backward(ctx, *gouts)
+
+    @staticmethod
+    def _backward(ctx, *gouts):
         from . import backward as bw
         k = ctx.keep
         unet, dtype, B = k["unet"], k["dtype"], k["B"]

@@ -15,7 +15,7 @@ python tools/precision_report.py > $O/precision.txt 2>&1; tail -3 $O/precision.t
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/ddp_check.py > $O/ddp_check_raw.txt 2>&1; grep -v "^\[W\|Gloo\|amdgpu.ids" $O/ddp_check_raw.txt > $O/ddp_check.txt; tail -2 $O/ddp_check.txt
 python tools/bench_optim.py > $O/optim.txt 2>&1; cat $O/optim.txt
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-alt-dtype --no-calib --pipeline 0 --streams 1 > $O/stats.log 2>&1)
-python tools/kstats.py $O/stats 25 > $O/kernel_stats.txt 2>&1; head -12 $O/kernel_stats.txt; (python tools/last_replay.py $O/stats --expect 368 || true) > $O/last_replay.txt; head -30 $O/last_replay.txt
+python tools/kstats.py $O/stats 25 > $O/kernel_stats.txt 2>&1; head -12 $O/kernel_stats.txt; (python tools/last_replay.py $O/stats --expect 377 || true) > $O/last_replay.txt; head -30 $O/last_replay.txt
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -- python3 $R/bench.py --workload train --steps 2 --warmup 1 > $O/stats_train.log 2>&1)
 python tools/kstats.py $O/stats_train 3 40 > $O/kernel_stats_train.txt 2>&1; head -14 $O/kernel_stats_train.txt
 bash tools/pmc.sh $tag/pmc $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-profile --no-alt-dtype --no-calib --no-graph
