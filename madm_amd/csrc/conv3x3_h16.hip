@@ -582,25 +582,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_h16_kernel(const IgemmP p, con
         if (ck + 1 < ck1) {
             __builtin_amdgcn_s_barrier();     // single halo buffer: every wave has read its last fragments of this chunk
             H16_DMA_HALO(ck + 1);
-#ifdef H16_RES_PREFETCH
-            // experiment (tools/build_variant.sh h16respf conv3x3_h16.hip -DH16_RES_PREFETCH): the epilogue's residual tile (64 KB per block,
-            // cold: +4 us per block in the real-time stamps) is touched here, one dword per 128-byte line, by LDS-DMA into a 256-byte
-            // scratch nobody reads -- no destination registers; its latency rides on the wait for the last chunk's halo
-            if (WIDE && p.residual && ck + 2 == ck1) {
-                const size_t rb_ = (size_t)p.M * (size_t)p.ldr * sizeof(T);
-                const __amdgpu_buffer_rsrc_t rsr_ = __builtin_amdgcn_make_buffer_rsrc(
-                    (void*)p.residual, 0, (unsigned)(rb_ < 0xffffffffull ? rb_ : 0xffffffffull), 0x00020000);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int l_ = (wave * 2 + i) * 64 + lane;              // line 0 .. 511 of the [256 pixel][256 B] tile
-                    const int px_ = l_ >> 1;
-                    const int oy_ = py0 + (px_ >> 4), ox_ = px0 + (px_ & 15);
-                    unsigned off_ = (unsigned)((((size_t)(b * p.OH + oy_) * p.OW + ox_) * p.ldr + n0) * sizeof(T)) + (unsigned)(l_ & 1) * 128u;
-                    if (oy_ >= p.OH || ox_ >= p.OW) off_ = OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsr_, lds0 + HALO_B + 2 * W_B + 256, 4, off_, 0, 0, 0);
-                }
-            }
-#endif
         }
     }
 #undef H16_DMA_HALO
@@ -636,11 +617,7 @@ namespace {
 template <typename T, int BN, bool FUSE, bool WIDE, bool SK = false>
 int launch_h16_one(const IgemmP& p0, hipStream_t s) {
     IgemmP p = p0;
-#ifdef H16_RES_PREFETCH
-    constexpr size_t lds0 = (size_t)((H16_PIX + 7) / 8) * 1024 + 2 * (size_t)BN * 128 + 32 * sizeof(float2) + 256;   // + the prefetch scratch
-#else
     constexpr size_t lds0 = (size_t)((H16_PIX + 7) / 8) * 1024 + 2 * (size_t)BN * 128 + 32 * sizeof(float2);
-#endif
     // experiment (MADM_EXP_H16_LDS=<bytes>): ask for more LDS than the kernel uses, e.g. 90112 -> ONE workgroup per CU, the
     // rest of the CU stays free for the workgroups of kernels on other streams (staged pipeline)
     static const size_t lds_exp = [] { const char* e = getenv("MADM_EXP_H16_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
