@@ -41,6 +41,8 @@ def test_kernel_suite_under_hbm_poison(cuda, mode):
     the fresh-process soak, this test keeps the kernel-level subset and the staged-pipeline equality test in the suite)."""
     targets = [os.path.join(HERE, "test_ops_gpu.py"), os.path.join(HERE, "test_labels_gpu.py"),
                os.path.join(HERE, "test_parity_gpu.py") + "::test_golden"]
+    if mode == "2":      # the huge-finite pattern: the kernel-level file only (the NaN mode carries the end-to-end cases; suite time)
+        targets = targets[:1]
     r, tail = _run_under({"MADM_DEBUG_POISON_HBM": mode}, targets, ["-k", "not full_t0"])
     assert r.returncode == 0, f"a kernel reads HBM nobody wrote (or the harness failed):\n{tail}\n{r.stderr[-2000:]}"
     assert " passed" in tail
