@@ -228,7 +228,7 @@ lib = _load()
 
 
 class _PoisonedLib:
-    """Debug harness (MADM_DEBUG_POISON_LDS=1; tests/test_ops_gpu.py::test_suite_under_lds_poison drives it): every launch
+    """Debug harness (MADM_DEBUG_POISON_LDS=1; tests/test_poison_gpu.py drives it): every launch
     through the C ABI is preceded, on the same stream, by madm_debug_poison_lds -- all LDS of the chip holds quiet NaNs when
     the kernel starts.  A kernel that reads LDS it did not write then fails its parity test deterministically; without the
     harness such a read returns whatever the previous kernel on that CU left there (a dependence on history)."""

@@ -14,17 +14,6 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_kernel_suite_under_lds_poison(cuda):
-    env = dict(os.environ, MADM_DEBUG_POISON_LDS="1")
-    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
-           os.path.join(HERE, "test_ops_gpu.py"), os.path.join(HERE, "test_labels_gpu.py"),
-           os.path.join(HERE, "test_parity_gpu.py") + "::test_golden", "-k", "not full_t0"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
-    tail = "\n".join(r.stdout.splitlines()[-15:])
-    assert r.returncode == 0, f"kernels depend on LDS they did not write (or the harness failed):\n{tail}\n{r.stderr[-2000:]}"
-    assert " passed" in tail
-
-
 def _run_under(env_extra, targets, extra=()):
     env = dict(os.environ, **env_extra)
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", *targets, *extra]
@@ -32,18 +21,26 @@ def _run_under(env_extra, targets, extra=()):
     return r, "\n".join(r.stdout.splitlines()[-25:])
 
 
-@pytest.mark.parametrize("mode", ["1", "2"], ids=["nan", "huge"])
-def test_kernel_suite_under_hbm_poison(cuda, mode):
-    """The HBM counterpart (madm_amd/_debug.py, MADM_DEBUG_POISON_HBM): every torch.empty-style device allocation of the process
-    and the split-K workspace on every hand-out hold NaNs (mode 1) / a huge finite pattern (mode 2) until a kernel writes them;
-    graph captures carry the fills as nodes.  A padded column, partial-tile tail or workspace slab that is read before it is
-    written fails the parity tests deterministically (VERDICT r5 'do this' 1; tools/exp/r6_poison_hbm.sh runs the WHOLE suite +
-    the fresh-process soak, this test keeps the kernel-level subset and the staged-pipeline equality test in the suite)."""
+def test_kernel_suite_under_lds_and_hbm_poison(cuda):
+    """Both harnesses at once (they are independent; one subprocess instead of two keeps the suite's time down): every launch
+    through the C ABI is preceded by an LDS poison (all 160 KB of every CU hold quiet NaNs when the kernel starts), and every
+    uninitialised device allocation of the process + the split-K workspace on every hand-out hold NaNs until written
+    (madm_amd/_debug.py, MADM_DEBUG_POISON_HBM=1; graph captures carry the fills as nodes).  A kernel that reads LDS it did not
+    write, a padded column, a partial tile's tail or a workspace slab nobody wrote fails its parity test deterministically
+    (VERDICT r5 'do this' 1; tools/exp/r6_poison_hbm.sh ran the WHOLE suite under the HBM poison + the fresh-process soak:
+    profiles/round6_hbm_poison.txt)."""
     targets = [os.path.join(HERE, "test_ops_gpu.py"), os.path.join(HERE, "test_labels_gpu.py"),
                os.path.join(HERE, "test_parity_gpu.py") + "::test_golden"]
-    if mode == "2":      # the huge-finite pattern: the kernel-level file only (the NaN mode carries the end-to-end cases; suite time)
-        targets = targets[:1]
-    r, tail = _run_under({"MADM_DEBUG_POISON_HBM": mode}, targets, ["-k", "not full_t0"])
+    r, tail = _run_under({"MADM_DEBUG_POISON_LDS": "1", "MADM_DEBUG_POISON_HBM": "1"}, targets, ["-k", "not full_t0"])
+    assert r.returncode == 0, f"a kernel reads LDS / HBM nobody wrote (or a harness failed):\n{tail}\n{r.stderr[-2000:]}"
+    assert " passed" in tail
+
+
+def test_kernel_suite_under_hbm_poison_huge_finite(cuda):
+    """MADM_DEBUG_POISON_HBM=2: 1e30 / 6e4 instead of NaN -- NaN x 0 and 1e30 x 0 differ: a zero-weighted read of a padded column
+    survives the finite pattern and not the NaN one (which the test above covers), so the two modes together tell 'read but
+    multiplied by zero' from 'read and used'.  The kernel-level file only (suite time)."""
+    r, tail = _run_under({"MADM_DEBUG_POISON_HBM": "2"}, [os.path.join(HERE, "test_ops_gpu.py")])
     assert r.returncode == 0, f"a kernel reads HBM nobody wrote (or the harness failed):\n{tail}\n{r.stderr[-2000:]}"
     assert " passed" in tail
 
