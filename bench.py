@@ -465,28 +465,35 @@ def run(args, model, call, ldm, rank, world, device, dist, mdist, pool):
     def capture_whole_forward(nstreams, nexec):
         """Whole-forward hipGraph executables over ONE fixed batch, round-robin on ``nstreams`` streams (reference points and
         profiling runs; the product runners are pipeline.StagedExtractor / GraphedInference)."""
+        import contextlib
+        from madm_amd import ops as _ops
+        # several executables side by side = a throughput mode: pinned to the throughput rows of the tile table like the product
+        # runners; ONE executable = the graph of a synchronous forward() (it opens the latency profile by itself)
+        prof = _ops.tuning_profile("throughput", pin=True) if (nstreams > 1 or nexec > 1) else contextlib.nullcontext()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), prof:
             model(*call)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         sts = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams >= 1 else [None]
         gs, os_ = [], []
-        for i in range(nexec):
-            g = torch.cuda.CUDAGraph()
-            st = sts[i % len(sts)]
-            if st is not None:
-                st.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(st):
-                    model(*call)          # sizes this stream's split-K workspace outside the capture
-                st.synchronize()
-                with torch.cuda.graph(g, stream=st):
-                    os_.append(model(*call))
-            else:
-                with torch.cuda.graph(g):
-                    os_.append(model(*call))
-            gs.append(g)
+        prof = _ops.tuning_profile("throughput", pin=True) if (nstreams > 1 or nexec > 1) else contextlib.nullcontext()
+        with prof:
+            for i in range(nexec):
+                g = torch.cuda.CUDAGraph()
+                st = sts[i % len(sts)]
+                if st is not None:
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        model(*call)          # sizes this stream's split-K workspace outside the capture
+                    st.synchronize()
+                    with torch.cuda.graph(g, stream=st):
+                        os_.append(model(*call))
+                else:
+                    with torch.cuda.graph(g):
+                        os_.append(model(*call))
+                gs.append(g)
         return gs, os_, sts
 
     def serial_reference(g, st):
