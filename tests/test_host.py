@@ -437,3 +437,27 @@ def test_tuning_profiles_switch_rows_and_pin():
         assert lib.madm_get_tuning_profile() == (1 if ops.SYNC_PROFILE == "latency" else 0)
     assert lib.madm_set_tuning_profile(7) != 0 and b"profile" in lib.madm_last_error()
     assert lib.madm_get_tuning_profile() == 0
+
+
+def test_stream_safe_cache_and_side_build_hooks_are_inert_on_the_host():
+    """Round 6: the lazily-built-constant cache and the side-stream build hook must cost nothing where no second
+    stream exists: CPU tensors carry no event, a hit returns the SAME object, ``note_build`` outside ``side_builds`` does nothing."""
+    import torch
+    from madm_amd import ops
+    from madm_amd.ldm_rocm import _StreamSafeCache
+    c = _StreamSafeCache()
+    n0 = _StreamSafeCache.fills
+    built = []
+
+    def build():
+        built.append(1)
+        return torch.arange(4)
+
+    a = c.get_or_build(("k", 1), build)
+    b = c.get_or_build(("k", 1), build)
+    assert a is b and len(built) == 1 and _StreamSafeCache.fills == n0 + 1 and c[("k", 1)][1] is None
+    t = c.get_or_build(("pair",), lambda: (torch.ones(1), torch.zeros(1)))
+    assert isinstance(t, tuple) and c.get_or_build(("pair",), lambda: None) is t
+    before = ops.SIDE_BUILDS_NOTED
+    ops.note_build()                                    # no side_builds context: nothing happens, no CUDA call
+    assert ops.SIDE_BUILDS_NOTED == before and ops._SIDE_BUILD_MAIN is None
