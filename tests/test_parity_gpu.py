@@ -593,3 +593,33 @@ def test_bench_workloads_have_tuned_rows(cuda):
             rows.append(f"{{1, {g.group(2)}, {g.group(3)}, {g.group(4)}, {g.group(5)}, {var}, {tile}, {sk}}},   "
                         f"// {'/'.join(sorted(tags))}: {flop / 1e9:.2f} GFLOP, no row (heuristic choice pinned)")
         raise AssertionError(f"{len(rows)} launch shapes of the bench workloads are not in the tuned table:\n" + "\n".join(rows))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["f16", "f32"])
+def test_latency_and_throughput_profiles_agree_at_bench_size(extractor, dtype):
+    """Round 6: a synchronous forward() consults the lone-launch rows of the tile / split-K table (latency profile), the
+    runners the throughput rows.  Other tiles, other split-K factors -- the same sums in another order: at the bench's own size
+    (2 x 3 x 512 x 512, where the 58 latency rows apply) the two profiles must agree to summation-order noise, in the timed
+    arithmetic (f16) and in the exact-f32 mode; and the profiles really differ (some launch takes another tile)."""
+    from madm_amd import ops
+    m = extractor
+    m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = dtype
+    b = _distinct_batches(1, 2, 512, 512)[0]
+    res, tiles = {}, {}
+    for name in ("throughput", "latency"):
+        ops.TILE_LOG = []
+        try:
+            with torch.no_grad(), ops.tuning_profile(name, pin=True):
+                res[name] = [f.float().clone() for f in m(b, "rgb")]
+            torch.cuda.synchronize()
+            tiles[name] = [(d, t, sk) for d, t, sk, _, _ in ops.TILE_LOG]
+        finally:
+            ops.TILE_LOG = None
+    assert len(tiles["latency"]) == len(tiles["throughput"]) > 100
+    moved = sum(1 for a_, b_ in zip(tiles["latency"], tiles["throughput"]) if a_ != b_)
+    assert moved >= 10, f"only {moved} launches differ between the two profiles"
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-3      # f16: one extra rounding of differently ordered partial sums per layer
+    for i, (x, y) in enumerate(zip(res["latency"], res["throughput"])):
+        e, l2 = rel_err(x.cpu(), y.cpu())
+        print(dtype, f"tap{i}: latency vs throughput profile max {e:.2e} l2 {l2:.2e} ({moved} launches take another tile / split-K)")
+        assert l2 < tol, (i, e, l2)
