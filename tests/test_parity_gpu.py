@@ -600,7 +600,8 @@ def test_latency_and_throughput_profiles_agree_at_bench_size(extractor, dtype):
     """Round 6: a synchronous forward() consults the lone-launch rows of the tile / split-K table (latency profile), the
     runners the throughput rows.  Other tiles, other split-K factors -- the same sums in another order: at the bench's own size
     (2 x 3 x 512 x 512, where the 58 latency rows apply) the two profiles must agree to summation-order noise, in the timed
-    arithmetic (f16) and in the exact-f32 mode; and the profiles really differ (some launch takes another tile)."""
+    arithmetic (f16), and the profiles really differ there (120 launches take another tile / split-K); the exact-f32 mode has no rows of its
+    own in either table and must be bit-identical under both."""
     from madm_amd import ops
     m = extractor
     m.compute_dtype = m.vae.compute_dtype = m.unet.compute_dtype = dtype
@@ -617,8 +618,14 @@ def test_latency_and_throughput_profiles_agree_at_bench_size(extractor, dtype):
             ops.TILE_LOG = None
     assert len(tiles["latency"]) == len(tiles["throughput"]) > 100
     moved = sum(1 for a_, b_ in zip(tiles["latency"], tiles["throughput"]) if a_ != b_)
+    if dtype == torch.float32:      # the tables hold rows of the 16-bit modes only: the f32 mode takes the same launches under both
+        assert moved == 0 and all(torch.equal(x, y) for x, y in zip(res["latency"], res["throughput"]))
+        return
     assert moved >= 10, f"only {moved} launches differ between the two profiles"
-    tol = 2e-5 if dtype == torch.float32 else 1.5e-3      # f16: one extra rounding of differently ordered partial sums per layer
+    # f16 storage: every layer output is rounded once, and a different summation order decorrelates those roundings -- two f16 forwards
+    # of ~60 layers sit ~sqrt(2) x (the per-forward storage noise of ~1e-3) apart (observed 1.5e-3, MI355X; the golden gate of one
+    # forward against fp32 is 3.75e-3)
+    tol = 3e-3
     for i, (x, y) in enumerate(zip(res["latency"], res["throughput"])):
         e, l2 = rel_err(x.cpu(), y.cpu())
         print(dtype, f"tap{i}: latency vs throughput profile max {e:.2e} l2 {l2:.2e} ({moved} launches take another tile / split-K)")
